@@ -1,0 +1,441 @@
+// train.hip — fused optimiser step for triplet-comparison MF on gfx950 (streaming form).
+//
+// One launch = one optimiser step of the reference loop (structure.py:847-851):
+//   gather U[u],V[i],V[j] -> x -> sigmoid -> BCE backward coefficient g_t
+//   -> row gradients accumulated in LDS (no dense gradient in HBM)
+//   -> dense Adam with coupled L2 over every element (torch/optim/adam.py _single_tensor_adam).
+//
+// Ownership decomposition (no inter-workgroup communication inside a launch):
+//   workgroup b owns a fixed flat range of E elements of one table (U or V) and the Adam moments
+//   of that range.  It scans the batch (B 16-byte records), and for every sample that touches one
+//   of its rows recomputes that sample's x_t from the INPUT copy of the tables and accumulates the
+//   row gradient in LDS, in batch order (deterministic; all contributions to one row are handled
+//   by one wave).  Parameters are ping-ponged (read Uin/Vin, write Uout/Vout) so that a workgroup
+//   may read rows other workgroups are updating in the same launch; m and v are updated in place.
+//   HBM traffic per element is the 24-byte minimum: read p,m,v, write p,m,v.
+//
+// Roofline: HBM-bound streaming; algorithmic bytes per step = 24*(n+m)*d + 12*B*d + 16*B.
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct AdamConst {
+    float w1;   // 1 - beta1
+    float b2;   // beta2
+    float w2;   // 1 - beta2
+    float eps;
+    float wd;
+    float neg_step_size;  // -(lr / (1 - beta1^t))   (f64 on the host, then fp32)
+    float bc2_sqrt;       // sqrt(1 - beta2^t)
+};
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+    using T = float4;
+};
+template <>
+struct Vec<1> {
+    using T = float;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float *p, float (&r)[VEC])
+{
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    } else {
+        r[0] = *p;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float *p, const float (&r)[VEC])
+{
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+        *p = r[0];
+    }
+}
+
+// E = 256 * VEC * CHUNKS elements per workgroup.
+template <int VEC, int CHUNKS>
+__global__ __launch_bounds__(256) void train_step_kernel(
+    const float *__restrict__ Uin, const float *__restrict__ Vin, float *__restrict__ Uout,
+    float *__restrict__ Vout, float *__restrict__ mU, float *__restrict__ vU, float *__restrict__ mV,
+    float *__restrict__ vV, const mfcd_sample *__restrict__ batch, const float *__restrict__ g_in,
+    int Bk, float inv_batch, int n, int m, int d, int blocksU, AdamConst ac,
+    float *__restrict__ loss_terms)
+{
+    constexpr int E = 256 * VEC * CHUNKS;
+    extern __shared__ __attribute__((aligned(16))) float sg[];  // [(row_hi-row_lo)*d] sparse row gradients
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool isV = (int)blockIdx.x >= blocksU;
+    const int tb = isV ? (int)blockIdx.x - blocksU : (int)blockIdx.x;
+    const int64_t cnt = (int64_t)(isV ? m : n) * d;
+    const int64_t e0 = (int64_t)tb * E;
+    const int64_t e1 = (e0 + E < cnt) ? e0 + E : cnt;
+    const int row_lo = (int)(e0 / d);
+    const int row_hi = (int)((e1 + d - 1) / d);
+    const int sg_off = (int)(e0 - (int64_t)row_lo * d);  // position of element e0 inside sg
+
+    const float *__restrict__ Pin = isV ? Vin : Uin;
+    float *__restrict__ Pout = isV ? Vout : Uout;
+    float *__restrict__ M1 = isV ? mV : mU;
+    float *__restrict__ M2 = isV ? vV : vU;
+
+    // ---- phase 0: put this workgroup's p, m, v loads in flight before touching the batch ----
+    float pr[CHUNKS][VEC], mr[CHUNKS][VEC], vr[CHUNKS][VEC];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        const int64_t e = e0 + (int64_t)(c * 256 + tid) * VEC;
+        if (e < e1) {
+            load_vec<VEC>(Pin + e, pr[c]);
+            load_vec<VEC>(M1 + e, mr[c]);
+            load_vec<VEC>(M2 + e, vr[c]);
+        }
+    }
+
+    // ---- phase 1: which samples of the batch touch my rows? ----
+    int any = 0;
+    for (int base = 0; base < Bk; base += MFCD_WAVE) {
+        const int t = base + lane;
+        if (t < Bk) {
+            const mfcd_sample s = batch[t];
+            if (isV)
+                any |= (s.i >= row_lo && s.i < row_hi) | (s.j >= row_lo && s.j < row_hi);
+            else
+                any |= (s.u >= row_lo && s.u < row_hi);
+        }
+    }
+    any = __syncthreads_or(any);
+
+    if (any) {
+        const int nsg = (row_hi - row_lo) * d;
+        for (int k = tid; k < nsg; k += 256) sg[k] = 0.0f;
+        __syncthreads();
+        // every wave walks the batch in order and takes the rows congruent to its id (mod 4)
+        for (int base = 0; base < Bk; base += MFCD_WAVE) {
+            const int t = base + lane;
+            mfcd_sample s;
+            s.u = s.i = s.j = -1;
+            s.z = 0.0f;
+            if (t < Bk) s = batch[t];
+            const bool hu = !isV && s.u >= row_lo && s.u < row_hi && ((s.u - row_lo) & 3) == wave;
+            const bool hi = isV && s.i >= row_lo && s.i < row_hi && ((s.i - row_lo) & 3) == wave;
+            const bool hj = isV && s.j >= row_lo && s.j < row_hi && ((s.j - row_lo) & 3) == wave;
+            const unsigned long long mu = __ballot(hu), mi = __ballot(hi), mj = __ballot(hj);
+            unsigned long long mask = mu | mi | mj;
+            while (mask) {
+                const int tl = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int uu = __shfl(s.u, tl, MFCD_WAVE), ii = __shfl(s.i, tl, MFCD_WAVE),
+                          jj = __shfl(s.j, tl, MFCD_WAVE);
+                const float zz = __shfl(s.z, tl, MFCD_WAVE);
+                const float *ur = Uin + (int64_t)uu * d, *vi = Vin + (int64_t)ii * d,
+                            *vj = Vin + (int64_t)jj * d;
+                float g;
+                if (g_in) {
+                    g = g_in[base + tl];
+                } else {
+                    float acc = 0.0f;
+                    for (int k = lane; k < d; k += MFCD_WAVE) acc += ur[k] * (vi[k] - vj[k]);
+                    const float p = sigmoid_f32(wave_sum64(acc));
+                    g = bce_sigmoid_backward_f32(p, zz, inv_batch);
+                    // the workgroup that owns the first element of row u records the loss term
+                    if (((mu >> tl) & 1ull) && loss_terms && lane == 0) {
+                        const int64_t first = (int64_t)uu * d;
+                        if (first >= e0 && first < e1) loss_terms[base + tl] = bce_term_f32(p, zz);
+                    }
+                }
+                if ((mu >> tl) & 1ull) {
+                    float *dst = sg + (int64_t)(uu - row_lo) * d;
+                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += g * (vi[k] - vj[k]);
+                }
+                if ((mi >> tl) & 1ull) {
+                    float *dst = sg + (int64_t)(ii - row_lo) * d;
+                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += g * ur[k];
+                }
+                if ((mj >> tl) & 1ull) {
+                    float *dst = sg + (int64_t)(jj - row_lo) * d;
+                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += -(g * ur[k]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: dense Adam over my range ----
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        const int loc = (c * 256 + tid) * VEC;
+        const int64_t e = e0 + loc;
+        if (e < e1) {
+            float gs[VEC];
+            if (any) {
+                load_vec<VEC>(sg + sg_off + loc, gs);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) gs[q] = 0.0f;
+            }
+            float po[VEC], mo[VEC], vo[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float p = pr[c][q];
+                const float g = gs[q] + ac.wd * p;                 // grad.add(param, alpha=wd)
+                const float m1 = mr[c][q] + ac.w1 * (g - mr[c][q]);  // exp_avg.lerp_(grad, 1-beta1)
+                const float v1 = vr[c][q] * ac.b2 + ac.w2 * g * g;   // mul_(beta2).addcmul_(g,g,1-beta2)
+                const float den = sqrtf(v1) / ac.bc2_sqrt + ac.eps;
+                po[q] = p + ac.neg_step_size * (m1 / den);          // addcdiv_(exp_avg, denom, -step_size)
+                mo[q] = m1;
+                vo[q] = v1;
+            }
+            store_vec<VEC>(Pout + e, po);
+            store_vec<VEC>(M1 + e, mo);
+            store_vec<VEC>(M2 + e, vo);
+        }
+    }
+}
+
+// One wave per sample: sigmoid output, BCE term and backward coefficient (split DP form).
+__global__ __launch_bounds__(256) void coeff_kernel(const float *__restrict__ U, const float *__restrict__ V,
+                                                    const mfcd_sample *__restrict__ batch, int B, int d,
+                                                    float inv_batch, float *__restrict__ g_out,
+                                                    float *__restrict__ term_out, float *__restrict__ p_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= B) return;
+    const mfcd_sample s = batch[t];
+    const float p = sigmoid_f32(wave_score(U, V, s.u, s.i, s.j, d, lane));
+    if (lane == 0) {
+        if (g_out) g_out[t] = bce_sigmoid_backward_f32(p, s.z, inv_batch);
+        if (term_out) term_out[t] = bce_term_f32(p, s.z);
+        if (p_out) p_out[t] = p;
+    }
+}
+
+// out[k] = mean(terms[k*B .. min((k+1)*B,N))) — one wave per batch, fixed summation order.
+__global__ __launch_bounds__(64) void batch_mean_kernel(const float *__restrict__ terms, int64_t N, int B,
+                                                        float *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int64_t off = (int64_t)blockIdx.x * B;
+    const int b = (int)((N - off) < B ? (N - off) : B);
+    float acc = 0.0f;
+    for (int t = lane; t < b; t += MFCD_WAVE) acc += terms[off + t];
+    acc = wave_sum64(acc);
+    if (lane == 0) out[blockIdx.x] = acc / (float)b;
+}
+
+struct Plan {
+    int vec, chunks, E, blocksU, blocksV;
+    size_t lds;
+};
+
+Plan make_plan(const void *const *ptrs, int nptrs, int n, int m, int d)
+{
+    Plan pl;
+    bool al16 = (d % 4) == 0;
+    for (int k = 0; k < nptrs; ++k) al16 = al16 && ((reinterpret_cast<uintptr_t>(ptrs[k]) & 15u) == 0);
+    pl.vec = al16 ? 4 : 1;
+    const int64_t total = (int64_t)(n + m) * d;
+    pl.chunks = 1;
+    while (pl.chunks < 8 && total / (256 * pl.vec * pl.chunks) > 2048) pl.chunks *= 2;
+    pl.E = 256 * pl.vec * pl.chunks;
+    pl.blocksU = (int)(((int64_t)n * d + pl.E - 1) / pl.E);
+    pl.blocksV = (int)(((int64_t)m * d + pl.E - 1) / pl.E);
+    pl.lds = sizeof(float) * (size_t)(pl.E + 2 * d);
+    return pl;
+}
+
+AdamConst adam_const(double lr, double beta1, double beta2, double eps, double wd, int64_t step)
+{
+    // bias corrections in f64 as Python does (adam.py: 1 - beta**step, lr / bc1, bc2 ** 0.5)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamConst ac;
+    ac.w1 = (float)(1.0 - beta1);
+    ac.b2 = (float)beta2;
+    ac.w2 = (float)(1.0 - beta2);
+    ac.eps = (float)eps;
+    ac.wd = (float)wd;
+    ac.neg_step_size = (float)(-(lr / bc1));
+    ac.bc2_sqrt = (float)sqrt(bc2);
+    return ac;
+}
+
+template <int VEC, int CHUNKS>
+void launch_step(const Plan &pl, hipStream_t st, const float *Uin, const float *Vin, float *Uout, float *Vout,
+                 float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
+                 float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms)
+{
+    hipLaunchKernelGGL((train_step_kernel<VEC, CHUNKS>), dim3(pl.blocksU + pl.blocksV), dim3(256), pl.lds, st, Uin,
+                       Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, m, d, pl.blocksU, ac,
+                       loss_terms);
+}
+
+void dispatch_step(const Plan &pl, hipStream_t st, const float *Uin, const float *Vin, float *Uout, float *Vout,
+                   float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
+                   float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms)
+{
+#define MFCD_CASE(V, C)                                                                                         \
+    if (pl.vec == V && pl.chunks == C)                                                                          \
+        return launch_step<V, C>(pl, st, Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, m, \
+                                 d, ac, loss_terms);
+    MFCD_CASE(4, 1) MFCD_CASE(4, 2) MFCD_CASE(4, 4) MFCD_CASE(4, 8)
+    MFCD_CASE(1, 1) MFCD_CASE(1, 2) MFCD_CASE(1, 4) MFCD_CASE(1, 8)
+#undef MFCD_CASE
+}
+
+int check_common(const void *U, const void *V, int n, int m, int d)
+{
+    if (!U || !V || n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D) return MFCD_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(U) & 3u) || (reinterpret_cast<uintptr_t>(V) & 3u)) return MFCD_EALIGN;
+    return 0;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d)
+{
+    (void)B;
+    if (N < 0 || n <= 0 || m <= 0 || d <= 0) return 0;
+    return align256(sizeof(float) * (size_t)n * d) + align256(sizeof(float) * (size_t)m * d) +
+           align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
+}
+
+namespace {
+
+// Shared body of mfcd_train_steps / mfcd_train_steps_timed.  With `timing_us` set, every step launch is
+// bracketed by its own pair of HIP events on the launch stream and the host waits for them at the end.
+int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *samples,
+                    int64_t N, int B, int64_t step0, int n, int m, int d, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
+                    void *stream, float *timing_us)
+{
+    if (int rc = check_common(U, V, n, m, d)) return rc;
+    if (!mU || !vU || !mV || !vV || N < 0 || B <= 0 || step0 < 0) return MFCD_EINVAL;
+    if (N == 0) return 0;
+    if (!samples || !workspace) return MFCD_EINVAL;
+    if (workspace_bytes < mfcd_train_workspace_bytes(N, B, n, m, d)) return MFCD_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *Ualt = (float *)ws;
+    ws += align256(sizeof(float) * (size_t)n * d);
+    float *Valt = (float *)ws;
+    ws += align256(sizeof(float) * (size_t)m * d);
+    float *terms = (float *)ws;
+
+    const void *ptrs[] = {U, V, mU, vU, mV, vV, Ualt, Valt};
+    const Plan pl = make_plan(ptrs, 8, n, m, d);
+    const int64_t nsteps = (N + B - 1) / B;
+    std::vector<hipEvent_t> ev;
+    if (timing_us) {
+        ev.resize(2 * (size_t)nsteps);
+        for (auto &e : ev) MFCD_HIP_TRY(hipEventCreate(&e));
+    }
+    for (int64_t k = 0; k < nsteps; ++k) {
+        const int64_t off = k * B;
+        const int Bk = (int)((N - off) < B ? (N - off) : B);
+        const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step0 + k + 1);
+        const bool even = (k & 1) == 0;
+        if (timing_us) MFCD_HIP_TRY(hipEventRecord(ev[2 * k], st));
+        dispatch_step(pl, st, even ? U : Ualt, even ? V : Valt, even ? Ualt : U, even ? Valt : V, mU, vU, mV, vV,
+                      samples + off, nullptr, Bk, 1.0f / (float)Bk, n, m, d, ac, terms + off);
+        if (timing_us) MFCD_HIP_TRY(hipEventRecord(ev[2 * k + 1], st));
+    }
+    MFCD_HIP_TRY(hipGetLastError());
+    if (nsteps & 1) {
+        MFCD_HIP_TRY(hipMemcpyAsync(U, Ualt, sizeof(float) * (size_t)n * d, hipMemcpyDeviceToDevice, st));
+        MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(float) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
+    }
+    if (loss_per_step) {
+        hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms, N, B, loss_per_step);
+        MFCD_HIP_TRY(hipGetLastError());
+    }
+    if (timing_us) {
+        MFCD_HIP_TRY(hipEventSynchronize(ev.back()));
+        double sum = 0.0;
+        float mn = 1e30f, mx = 0.0f;
+        for (int64_t k = 0; k < nsteps; ++k) {
+            float ms = 0.0f;
+            MFCD_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
+            sum += ms;
+            mn = ms < mn ? ms : mn;
+            mx = ms > mx ? ms : mx;
+        }
+        timing_us[0] = (float)(sum / (double)nsteps * 1e3);
+        timing_us[1] = mn * 1e3f;
+        timing_us[2] = mx * 1e3f;
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mfcd_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                                const mfcd_sample *samples, int64_t N, int B, int64_t step0, int n, int m, int d,
+                                double lr, double beta1, double beta2, double eps, double weight_decay,
+                                float *loss_per_step, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return run_train_steps(U, V, mU, vU, mV, vV, samples, N, B, step0, n, m, d, lr, beta1, beta2, eps, weight_decay,
+                           loss_per_step, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int mfcd_train_steps_timed(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                                      const mfcd_sample *samples, int64_t N, int B, int64_t step0, int n, int m,
+                                      int d, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                      float *loss_per_step, void *workspace, size_t workspace_bytes, void *stream,
+                                      float *kernel_us_host)
+{
+    if (!kernel_us_host) return MFCD_EINVAL;
+    return run_train_steps(U, V, mU, vU, mV, vV, samples, N, B, step0, n, m, d, lr, beta1, beta2, eps, weight_decay,
+                           loss_per_step, workspace, workspace_bytes, stream, kernel_us_host);
+}
+
+extern "C" int mfcd_batch_coefficients(const float *U, const float *V, const mfcd_sample *samples, int B, int n,
+                                       int m, int d, int batch_divisor, float *g_out, float *term_out,
+                                       float *p_out, void *stream)
+{
+    if (int rc = check_common(U, V, n, m, d)) return rc;
+    if (B < 0 || batch_divisor <= 0) return MFCD_EINVAL;
+    if (B == 0) return 0;
+    if (!samples) return MFCD_EINVAL;
+    hipLaunchKernelGGL(coeff_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, U, V, samples, B, d,
+                       1.0f / (float)batch_divisor, g_out, term_out, p_out);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mfcd_apply_step(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                               const mfcd_sample *samples, const float *g, int B, int64_t step, int n, int m, int d,
+                               double lr, double beta1, double beta2, double eps, double weight_decay,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_common(U, V, n, m, d)) return rc;
+    if (!mU || !vU || !mV || !vV || B < 0 || step < 1 || !workspace) return MFCD_EINVAL;
+    if (B > 0 && (!samples || !g)) return MFCD_EINVAL;
+    if (workspace_bytes < mfcd_train_workspace_bytes(B, B, n, m, d)) return MFCD_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *Ualt = (float *)ws;
+    ws += align256(sizeof(float) * (size_t)n * d);
+    float *Valt = (float *)ws;
+    const void *ptrs[] = {U, V, mU, vU, mV, vV, Ualt, Valt};
+    const Plan pl = make_plan(ptrs, 8, n, m, d);
+    const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step);
+    dispatch_step(pl, st, U, V, Ualt, Valt, mU, vU, mV, vV, samples, g, B, 0.0f, n, m, d, ac, nullptr);
+    MFCD_HIP_TRY(hipGetLastError());
+    MFCD_HIP_TRY(hipMemcpyAsync(U, Ualt, sizeof(float) * (size_t)n * d, hipMemcpyDeviceToDevice, st));
+    MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(float) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
+    return 0;
+}

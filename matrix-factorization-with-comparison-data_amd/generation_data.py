@@ -1,0 +1,380 @@
+"""Host-side data preparation with the reference module's names (ref = reference generation_data.py).
+
+Triplet samplers and ground-truth generators are one-off host work outside the device hot path
+(SURVEY §8f rows N2/N3).  They keep the reference's names, arguments, return types, printed warnings
+and — where it is cheap — the same order of RNG draws, so seeded runs line up with the reference.
+`generate_embeddings` additionally has a factored large-scale form (`generate_embedding_factors`):
+the reference's O(n^3) full orthogonal matrices are only ever used through their first d columns.
+"""
+import math
+
+import numpy as np
+import torch
+
+# ------------------------------------------------------------------------------------------------
+# triplet samplers (ref:16-338): each returns a list of unique (u, i, j) tuples
+# ------------------------------------------------------------------------------------------------
+
+
+def _accept(t, i, j, exclude, found):
+    return i != j and t not in exclude and t not in found
+
+
+def choose_items_random(X, num_triplets, exclude):
+    """Uniform u, i, j (ref:16-26); one randint(n) and one randint(m, size 2) per attempt."""
+    n, m = X.shape
+    found = set()
+    while len(found) < num_triplets:
+        u = int(torch.randint(0, n, (1,)))
+        i, j = torch.randint(0, m, (2,)).tolist()
+        if _accept((u, i, j), i, j, exclude, found):
+            found.add((u, i, j))
+    return list(found)
+
+
+def choose_items_by_proximity(X, num_triplets, exclude, k=100):
+    """"Min-Max": i among the user's k best items, j among the k worst (ref:29-43)."""
+    n, m = X.shape
+    kk = min(k, m)
+    found, cache = set(), {}
+    while len(found) < num_triplets:
+        u = int(torch.randint(0, n, (1,)))
+        if u not in cache:
+            row = X[u]
+            cache[u] = (torch.topk(row, k=kk)[1].tolist(), torch.topk(-row, k=kk)[1].tolist())
+        best, worst = cache[u]
+        i, j = np.random.choice(best), np.random.choice(worst)
+        if _accept((u, i, j), i, j, exclude, found):
+            found.add((u, i, j))
+    return list(found)
+
+
+def choose_items_by_margin(X, num_triplets, exclude, max_attempts=5000_000):
+    """"Close-Call": |X[u,i]-X[u,j]| below an adaptive margin (ref:46-84).  Attempts are drawn in
+    blocks of 500 from an unseeded numpy Generator, capped at `max_attempts`, exactly as specified
+    there; the per-block filtering is vectorised."""
+    n, m = X.shape
+    exclude = exclude or set()
+    head = X[:min(10, n)].cpu().numpy()
+    margin = np.mean(head.max(axis=1) - head.min(axis=1)) * num_triplets / (n * m)
+    Xn = X.cpu().numpy()
+    rng = np.random.default_rng()
+    found, attempts, block = set(), 0, 500
+    while len(found) < num_triplets and attempts < max_attempts:
+        us = rng.integers(0, n, size=block)
+        ij = rng.integers(0, m, size=(block, 2))
+        close = (ij[:, 0] != ij[:, 1]) & (np.abs(Xn[us, ij[:, 0]] - Xn[us, ij[:, 1]]) <= margin)
+        for r in np.nonzero(close)[0]:
+            t = (us[r], ij[r, 0], ij[r, 1])
+            if t not in found and t not in exclude:
+                found.add(t)
+                if len(found) >= num_triplets:
+                    break
+        attempts += block
+    if len(found) < num_triplets:
+        print(f"⚠️ Only {len(found)} triplets generated (target={num_triplets}, margin={margin:.4f}) "
+              f"after {attempts} attempts.maximum : {np.max(Xn)}")
+    return list(found)
+
+
+def choose_items_by_variance(X, num_triplets, exclude):
+    """Items drawn proportionally to their variance across users (ref:87-99)."""
+    n, m = X.shape
+    var = torch.var(X, dim=0)
+    probs = var / var.sum()
+    found = set()
+    while len(found) < num_triplets:
+        u = int(torch.randint(0, n, (1,)))
+        i, j = torch.multinomial(probs, 2, replacement=False).tolist()
+        t = (u, i, j)
+        if t not in found and t not in exclude:
+            found.add(t)
+    return list(found)
+
+
+def _popularity_probs(m, method, alpha):
+    if method == "zipf":
+        w = 1.0 / (np.arange(1, m + 1) ** alpha)
+    elif method == "exponential":
+        w = np.exp(-alpha * np.arange(m))
+    elif method == "uniform":
+        w = np.ones(m)
+    else:
+        raise ValueError(f"Unknown popularity method: {method}")
+    return w / w.sum()
+
+
+def choose_items_by_popularity(X, num_triplets, exclude, method="zipf", alpha=1.5):
+    """i, j drawn without replacement from an item-popularity law over the item index (ref:103-128)."""
+    n, m = X.shape
+    probs = _popularity_probs(m, method, alpha)
+    items = np.arange(m)
+    found = set()
+    while len(found) < num_triplets:
+        u = int(torch.randint(0, n, (1,)))
+        i, j = np.random.choice(items, size=2, replace=False, p=probs).tolist()
+        if _accept((u, i, j), i, j, exclude, found):
+            found.add((u, i, j))
+    return list(found)
+
+
+def choose_items_by_svd_projection(X, num_triplets, exclude, rank=10, top_fraction=0.3):
+    """Users/items with the largest truncated-SVD projection norms (ref:131-179).  As there, `rank`
+    is overridden from the sampling density and at most 5*num_triplets attempts are made."""
+    import scipy.sparse.linalg as spla
+    n, m = X.shape
+    rank = int(num_triplets / (n * m) * max(n, m))
+    Us, S, Vt = spla.svds(X.cpu().numpy(), k=rank)
+    u_norm = np.linalg.norm(Us * S, axis=1)
+    i_norm = np.linalg.norm((Vt.T * S), axis=1)
+    top_users = np.argsort(u_norm)[-max(1, int(top_fraction * n)):]
+    top_items = np.argsort(i_norm)[-max(2, int(top_fraction * m)):]
+    rng = np.random.default_rng()
+    found = set()
+    for _ in range(num_triplets * 5):
+        u = int(rng.choice(top_users))
+        i, j = rng.choice(top_items, size=2, replace=False)
+        if _accept((u, i, j), i, j, exclude, found):
+            found.add((u, i, j))
+        if len(found) >= num_triplets:
+            break
+    if len(found) < num_triplets:
+        print(f"⚠️ Only {len(found)} triplets generated (target={num_triplets})")
+    return list(found)
+
+
+def estimate_k(num_triplets):
+    return math.ceil((1 + math.sqrt(1 + 8 * num_triplets)) / 2)
+
+
+def choose_items_top_k(X, num_triplets, exclude, k=None):
+    """"top_10%": both items among the user's k best, k = 10 % of the catalogue, >= 5 (ref:189-224)."""
+    n, m = X.shape
+    if k is None:
+        k = min(m, max(5, int(0.1 * m)))
+    found, cache = set(), {}
+    for _ in range(num_triplets * 3):
+        u = int(torch.randint(0, n, (1,)))
+        if u not in cache:
+            cache[u] = torch.topk(X[u], k=k).indices.tolist()
+        best = cache[u]
+        i = np.random.choice(best)
+        j = np.random.choice(best)
+        while i == j:
+            j = np.random.choice(best)
+        t = (u, i, j)
+        if t not in found and t not in exclude:
+            found.add(t)
+        if len(found) >= num_triplets:
+            break
+    if len(found) < num_triplets:
+        print(f"⚠️ Only {len(found)} triplets generated (target={num_triplets}, k={k})")
+    return list(found)
+
+
+def choose_items_cluster_based(X, num_triplets, exclude, n_clusters=20):
+    """i and j from two different k-means clusters of the item columns (ref:229-247)."""
+    from sklearn.cluster import KMeans
+    n, m = X.shape
+    labels = KMeans(n_clusters=n_clusters, n_init="auto").fit_predict(X.T.cpu().numpy())
+    members = {c: np.where(labels == c)[0] for c in range(n_clusters)}
+    ids = list(members)
+    found = set()
+    while len(found) < num_triplets:
+        u = int(torch.randint(0, n, (1,)))
+        c1, c2 = np.random.choice(ids, 2, replace=False)
+        i, j = np.random.choice(members[c1]), np.random.choice(members[c2])
+        if _accept((u, i, j), i, j, exclude, found):
+            found.add((u, i, j))
+    return list(found)
+
+
+def choose_items_by_user_similarity(X, num_triplets, exclude=None, max_attempts=10000, verbose=False,
+                                    fallback_random=False, error_if_incomplete=False):
+    """Contrast a user's favourite items with those of cosine-similar users (ref:251-338)."""
+    from sklearn.metrics.pairwise import cosine_similarity
+    n, m = X.shape
+    sim = cosine_similarity(X.cpu().numpy())
+    np.fill_diagonal(sim, -1.0)
+    exclude = exclude or set()
+    rng = np.random.default_rng()
+    n_neigh = min(20, max(3, num_triplets // n))
+    top_k = max(3, min(m // 10, 10 + num_triplets // (5 * n)))
+    if verbose:
+        print(f"→ Adaptive config: top_k={top_k}, neighbors/user={n_neigh}, target={num_triplets}")
+    favourites = torch.topk(X, k=min(top_k, m), dim=1).indices.tolist()
+    found, attempts = set(), 0
+    while len(found) < num_triplets and attempts < max_attempts:
+        u = rng.integers(0, n)
+        mine = set(favourites[u])
+        for v in np.argsort(-sim[u])[:n_neigh]:
+            theirs = set(favourites[v])
+            only_u, only_v = list(mine - theirs), list(theirs - mine)
+            if only_u and only_v:
+                i, j = rng.choice(only_u), rng.choice(only_v)
+            elif len(mine) >= 2:
+                i, j = rng.choice(list(mine), size=2, replace=False)
+            else:
+                continue
+            t = (u, i, j)
+            if i != j and t not in found and t not in exclude:
+                found.add(t)
+                break
+        attempts += 1
+        if verbose and attempts % 1000 == 0:
+            print(f"{len(found)} triplets generated after {attempts} attempts.")
+    if len(found) < num_triplets:
+        msg = f"⚠️ Only {len(found)} triplets generated (target={num_triplets}) after {attempts} attempts."
+        if error_if_incomplete:
+            raise RuntimeError(msg)
+        if fallback_random:
+            found.update(choose_items_random(X, num_triplets - len(found), exclude=found | exclude))
+        else:
+            print(msg)
+    if verbose:
+        print(f"✅ Returned {len(found)} triplets.")
+    return list(found)
+
+
+# ------------------------------------------------------------------------------------------------
+# ground-truth generators (ref:346-715)
+# ------------------------------------------------------------------------------------------------
+def generate_embeddings(n, m, d, device="cpu"):
+    """"base" X (ref:346-370): Q_n diag(1/sqrt(d) on the first d) Q_m^T * sqrt(nm)/2 with Haar orthogonal
+    Q_n, Q_m drawn (in this order) by scipy's ortho_group from numpy's global RNG.  Only the first d
+    columns of each matter, so the product is formed from the n x d and m x d slices."""
+    from scipy.stats import ortho_group
+    A = ortho_group.rvs(dim=n)[:, :d]
+    B = ortho_group.rvs(dim=m)[:, :d]
+    X = (A / np.sqrt(d)) @ B.T * (np.sqrt(n * m) / 2)
+    return torch.tensor(X, dtype=torch.float32, device=device)
+
+
+def generate_embedding_factors(n, m, d, device="cpu", generator=None):
+    """Large-scale form of the "base" law: Haar n x d and m x d frames from the QR of Gaussian matrices
+    (sign-fixed), O((n+m) d^2) instead of O(n^3).  X = A @ B.T with A = Q_n sqrt(nm)/(2 sqrt(d))."""
+    def frame(rows):
+        G = torch.randn(rows, d, dtype=torch.float64, generator=generator)
+        Q, R = torch.linalg.qr(G)
+        return Q * torch.sign(torch.diagonal(R))
+    A = frame(n) * (math.sqrt(n * m) / (2 * math.sqrt(d)))
+    return A.float().to(device), frame(m).float().to(device)
+
+
+def generate_low_rank_matrix(n, m, d, rank, device="cpu"):
+    """Orthonormal n x d, m x d frames and a 0/1 spectrum with `rank` ones (ref:373-391)."""
+    from scipy.stats import ortho_group
+    A = torch.tensor(ortho_group.rvs(dim=n)[:, :d], dtype=torch.float32, device=device)
+    B = torch.tensor(ortho_group.rvs(dim=m)[:, :d], dtype=torch.float32, device=device)
+    S = torch.zeros(d)
+    S[:rank] = 1.0
+    return A, B, S.to(device) if torch.device(device).type != "cpu" else S
+
+
+def generate_clustered_matrix_from_embeddings(n, m, d, n_clusters=5, device="cpu", scale=1.0, shift_strength=0.5):
+    """"base" X whose item columns are pulled towards their k-means cluster mean (ref:394-434)."""
+    from sklearn.cluster import KMeans
+    X = generate_embeddings(n, m, d, device="cpu").numpy()
+    labels = KMeans(n_clusters=n_clusters, n_init="auto", random_state=42).fit_predict(X.T)
+    out = X.copy()
+    for c in range(n_clusters):
+        cols = np.where(labels == c)[0]
+        if len(cols):
+            out[:, cols] = (1 - shift_strength) * X[:, cols] + shift_strength * X[:, cols].mean(axis=1, keepdims=True)
+    return torch.tensor(out, dtype=torch.float32, device=device) * scale
+
+
+def generate_structured_embeddings(n, m, d, num_clusters=5, cluster_std=0.1, device="cpu"):
+    """Items scattered around cluster centres, users as mixtures of the centres (ref:437-467)."""
+    centres = torch.randn(num_clusters, d, device=device)
+    assign = torch.randint(0, num_clusters, (m,))
+    V = centres[assign.to(centres.device)] + cluster_std * torch.randn(m, d, device=device)
+    U = torch.randn(n, num_clusters, device=device) @ centres
+    return U, V
+
+
+def generate_svd_embeddings(n, m, d, noise_level=0.1, device="cpu"):
+    """Top-d SVD factors of a Gaussian matrix, sqrt-spectrum on both sides, plus noise (ref:470-502)."""
+    Uf, S, Vf = torch.svd(torch.randn(n, m, device=device))
+    root = torch.sqrt(S[:d])
+    U, V = Uf[:, :d] * root, Vf[:, :d] * root
+    U = U + noise_level * torch.randn_like(U)
+    V = V + noise_level * torch.randn_like(V)
+    return U.to(device), V.to(device)
+
+
+def generate_correlated_embeddings(n, m, d, correlation_factor=0.8, device="cpu"):
+    """Gaussian factors mixed by (1-c) I + c 11^T, divided by d (ref:505-534)."""
+    U, V = torch.randn(n, d, device=device), torch.randn(m, d, device=device)
+    C = torch.eye(d, device=device) * (1 - correlation_factor) + correlation_factor * torch.ones((d, d), device=device)
+    return (U @ C) / d, (V @ C) / d
+
+
+def _smooth_over_graph(U, influence):
+    """In-place sequential neighbour averaging on a Watts-Strogatz(k=5, p=0.1) graph (ref:567-574, 610-617)."""
+    import networkx as nx
+    G = nx.watts_strogatz_graph(U.shape[0], k=5, p=0.1)
+    for u in range(U.shape[0]):
+        friends = list(G.neighbors(u))
+        if friends:
+            U[u] = (1 - influence) * U[u] + influence * U[friends].mean(dim=0)
+    return U
+
+
+def generate_graph_embeddings(n, m, d, device="cpu"):
+    """Two socially-smoothed signal dimensions + 0.1-scale noise dimensions; V / sqrt(d) (ref:539-585)."""
+    d_eff = min(d, 2)
+    U_low, V_low = torch.randn(n, d_eff, device=device), torch.randn(m, d_eff, device=device)
+    U_low = _smooth_over_graph(U_low, 0.3)
+    U = torch.cat([U_low, 0.1 * torch.randn(n, d - d_eff, device=device)], dim=1)
+    V = torch.cat([V_low, 0.1 * torch.randn(m, d - d_eff, device=device)], dim=1)
+    return U, V / np.sqrt(d)
+
+
+def generate_social_embeddings(n, m, d, social_influence=0.5, device="cpu"):
+    """Gaussian users smoothed over a small-world graph, U / log(d+1) (ref:588-619)."""
+    U, V = torch.randn(n, d, device=device), torch.randn(m, d, device=device)
+    return _smooth_over_graph(U, social_influence) / np.log(d + 1), V
+
+
+def generate_temporal_embeddings(n, m, d, timesteps=5, device="cpu"):
+    """Base factors plus `timesteps` x 0.02-scale drift; V / sqrt(d) (ref:622-651)."""
+    U0, V0 = torch.randn(n, d, device=device), torch.randn(m, d, device=device)
+    U = U0 + timesteps * (torch.randn(n, d, device=device) * 0.02)
+    V = V0 + timesteps * (torch.randn(m, d, device=device) * 0.02)
+    return U, V / np.sqrt(d)
+
+
+def generate_hierarchical_embeddings(n, m, d, num_groups=5, device="cpu"):
+    """Users = group centre + 10 x Gaussian; V / log(d+1) (ref:653-683)."""
+    groups = torch.randn(num_groups, d, device=device)
+    assign = torch.randint(0, num_groups, (n,))
+    U = groups[assign.to(groups.device)] + 10 * torch.randn(n, d, device=device)
+    return U, torch.randn(m, d, device=device) / np.log(d + 1)
+
+
+def generate_gmm_embeddings(n, m, d, num_clusters=5, device="cpu"):
+    """Every user/item snapped to the mean of its Gaussian-mixture component; note both use the means
+    of the SECOND fit, as in the reference (ref:686-715)."""
+    from sklearn.mixture import GaussianMixture
+    gmm = GaussianMixture(n_components=num_clusters, random_state=42)
+    uc = gmm.fit_predict(torch.randn(n, d).numpy())
+    ic = gmm.fit_predict(torch.randn(m, d).numpy())
+    return (torch.tensor(gmm.means_[uc], dtype=torch.float32, device=device),
+            torch.tensor(gmm.means_[ic], dtype=torch.float32, device=device))
+
+
+# ------------------------------------------------------------------------------------------------
+# unused preference helpers kept for name compatibility (ref:723-742)
+# ------------------------------------------------------------------------------------------------
+def sigmoid_preference(U, V, u, i, j, scale=1.0):
+    return int(torch.sigmoid(scale * torch.dot(U[u], V[i] - V[j])).item() > 0.5)
+
+
+def softmax_preference(U, V, u, i, j, temp=1.0):
+    probs = torch.softmax((V @ U[u]) / temp, dim=0)
+    return int(probs[i].item() > probs[j].item())
+
+
+def max_preference(U, V, u, i, j):
+    return int(torch.dot(U[u], V[i] - V[j]).item() > 0)

@@ -1,0 +1,76 @@
+"""ctypes binding of libmfcd_hip.so (C-ABI declared in include/mfcd.h).
+
+There is no fallback: if the HIP library is not built, or a call is made without a GPU tensor,
+this module raises.  PyTorch is used only to own device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libmfcd_hip.so")
+
+_vp, _i32, _i64, _dbl, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mfcd.h one to one
+SIGNATURES = {
+    "mfcd_abi_version": (_i32, []),
+    "mfcd_error_string": (ctypes.c_char_p, [_i32]),
+    "mfcd_check_samples": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "mfcd_eval_batches": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mfcd_train_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
+    "mfcd_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp, _sz, _vp]),
+    "mfcd_train_steps_timed": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
+                               [_vp, _vp, _sz, _vp, _vp]),
+    "mfcd_batch_coefficients": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mfcd_apply_step": (_i32, [_vp] * 8 + [_i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _sz, _vp]),
+    "mfcd_uvt_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "mfcd_uvt_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
+    "mfcd_uvt_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class MfcdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every declared symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfcdError(
+                f"{LIB_PATH} is missing: the HIP hot path has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or make -C csrc). "
+                "There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+        if lib.mfcd_abi_version() != 1:
+            raise MfcdError("libmfcd_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise MfcdError(load().mfcd_error_string(code).decode())
+
+
+def ptr(t):
+    """Raw device pointer of a CUDA(HIP) tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MfcdError("the HIP hot path needs tensors on a GPU device (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise MfcdError("the HIP hot path needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream

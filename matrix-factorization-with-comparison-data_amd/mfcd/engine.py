@@ -1,0 +1,203 @@
+"""Device-side driver of the hot path: owns nothing but a workspace; reads/writes the caller's
+model parameters and the caller's torch.optim.Adam state in place (the optimizer
+object stays valid after a fused run).
+
+All compute goes through the C-ABI in libmfcd_hip.so; there is no eager/torch fallback.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .batching import dataset_records, epoch_order, n_batches, pack_records
+
+
+def _require_cuda_param(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.MfcdError(f"{name} must live on a GPU device: the triplet hot path is MI355X-only "
+                             "(pass device='cuda'; there is no CPU fallback)")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.MfcdError(f"{name} must be a contiguous float32 tensor")
+
+
+class AdamBinding:
+    """View of a caller-owned torch.optim.Adam over exactly (model.U, model.V)."""
+
+    def __init__(self, model, optimizer):
+        if type(optimizer) is not torch.optim.Adam:
+            raise NotImplementedError("the fused step implements torch.optim.Adam only "
+                                      f"(got {type(optimizer).__name__})")
+        if len(optimizer.param_groups) != 1:
+            raise NotImplementedError("the fused step needs a single Adam param group")
+        g = optimizer.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or g.get("decoupled_weight_decay"):
+            raise NotImplementedError("amsgrad / maximize / differentiable / decoupled_weight_decay are not fused")
+        if isinstance(g["lr"], torch.Tensor) or any(isinstance(b, torch.Tensor) for b in g["betas"]):
+            raise NotImplementedError("tensor-valued lr / betas are not fused")
+        params = [p for p in g["params"]]
+        if len(params) != 2 or not any(p is model.U for p in params) or not any(p is model.V for p in params):
+            raise NotImplementedError("the optimizer must hold exactly model.U and model.V")
+        self.model, self.opt, self.group = model, optimizer, g
+        _require_cuda_param(model.U.data, "model.U")
+        _require_cuda_param(model.V.data, "model.V")
+        if model.U.shape[1] != model.V.shape[1]:
+            raise ValueError("U and V must share the latent dimension")
+        for p in (model.U, model.V):  # lazily created exactly as Adam._init_group does
+            st = optimizer.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.get_default_dtype())
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            _require_cuda_param(st["exp_avg"], "exp_avg")
+            _require_cuda_param(st["exp_avg_sq"], "exp_avg_sq")
+        su, sv = optimizer.state[model.U]["step"], optimizer.state[model.V]["step"]
+        if float(su) != float(sv):
+            raise NotImplementedError("U and V must have taken the same number of Adam steps")
+
+    @property
+    def step(self):
+        return int(float(self.opt.state[self.model.U]["step"]))
+
+    def advance(self, k):
+        for p in (self.model.U, self.model.V):
+            self.opt.state[p]["step"] += k
+
+    def hyper(self):
+        g = self.group
+        return float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"])
+
+    def tensors(self):
+        U, V = self.model.U.data, self.model.V.data
+        su, sv = self.opt.state[self.model.U], self.opt.state[self.model.V]
+        return U, V, su["exp_avg"], su["exp_avg_sq"], sv["exp_avg"], sv["exp_avg_sq"]
+
+
+class SampleStore:
+    """A dataset's (u,i,j,z) records resident in HBM as 16-byte mfcd_sample structs."""
+
+    def __init__(self, rows, n, m, device):
+        rec = pack_records(rows, n, m)
+        self.N = rec.shape[0]
+        self.host = rec
+        self.dev = torch.from_numpy(rec).to(device)  # int32 [N,4]
+        self.device = self.dev.device
+
+    @classmethod
+    def from_loader(cls, loader, n, m, device):
+        ds = loader.dataset
+        key = (id(getattr(ds, "data", ds)), len(ds), n, m, str(device))
+        cached = getattr(ds, "_mfcd_store", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        store = cls(dataset_records(ds), n, m, device)
+        try:
+            ds._mfcd_store = (key, store)
+        except AttributeError:
+            pass
+        return store
+
+    def ordered(self, order):
+        """Records gathered in `order` (an int64 CPU tensor) — the per-epoch stream, built on device."""
+        if order.numel() == self.N and bool((order[:1] == 0).all()) and order.numel() > 1 and \
+                bool((order[1:] - order[:-1] == 1).all()):
+            return self.dev
+        return self.dev.index_select(0, order.to(self.device, non_blocking=True))
+
+
+class Workspace:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_ws = Workspace()
+
+
+def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None):
+    """Run ceil(N/B) optimiser steps over `samples_dev` (int32 [N,4] device records, in order).
+    Returns the fp32 device tensor of per-step batch-mean losses.  No host sync — unless `kernel_us`
+    (a 3-element list) is given: then the diagnostic twin is used, which brackets every step launch
+    with HIP events, waits, and fills kernel_us with [avg, min, max] microseconds (bench.py only)."""
+    import ctypes
+    L = _lib.load()
+    U, V, mU, vU, mV, vV = binding.tensors()
+    (n, d), m = U.shape, V.shape[0]
+    N = samples_dev.shape[0]
+    nsteps = n_batches(N, batch_size)
+    if loss_out is None:
+        loss_out = torch.empty(max(nsteps, 1), dtype=torch.float32, device=U.device)
+    nbytes = L.mfcd_train_workspace_bytes(N, batch_size, n, m, d)
+    ws = _ws.get(nbytes, U.device)
+    lr, b1, b2, eps, wd = binding.hyper()
+    args = [_lib.ptr(U), _lib.ptr(V), _lib.ptr(mU), _lib.ptr(vU), _lib.ptr(mV), _lib.ptr(vV),
+            _lib.ptr(samples_dev), N, batch_size, binding.step, n, m, d, lr, b1, b2, eps, wd,
+            _lib.ptr(loss_out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(U.device)]
+    if kernel_us is None:
+        _lib.check(L.mfcd_train_steps(*args))
+    else:
+        out = (ctypes.c_float * 3)()
+        _lib.check(L.mfcd_train_steps_timed(*args, ctypes.cast(out, ctypes.c_void_p)))
+        kernel_us[:] = [float(out[0]), float(out[1]), float(out[2])]
+    binding.advance(nsteps)
+    return loss_out[:nsteps]
+
+
+def eval_batches(U, V, samples_dev, batch_size, want_p=False):
+    """Forward + BCE per batch.  Returns (loss_per_batch fp32, correct_per_batch int32, p or None), on device."""
+    L = _lib.load()
+    _require_cuda_param(U, "U")
+    _require_cuda_param(V, "V")
+    (n, d), m = U.shape, V.shape[0]
+    N = samples_dev.shape[0]
+    nb = n_batches(N, batch_size)
+    loss = torch.empty(max(nb, 1), dtype=torch.float32, device=U.device)
+    corr = torch.empty(max(nb, 1), dtype=torch.int32, device=U.device)
+    p = torch.empty(max(N, 1), dtype=torch.float32, device=U.device) if want_p else None
+    _lib.check(L.mfcd_eval_batches(_lib.ptr(U), _lib.ptr(V), _lib.ptr(samples_dev), N, batch_size, n, m, d,
+                                   _lib.ptr(loss), _lib.ptr(corr), _lib.ptr(p), _lib.stream_ptr(U.device)))
+    return loss[:nb], corr[:nb], (p[:N] if want_p else None)
+
+
+def python_float_sum(x):
+    """Sequential f64 accumulation of fp32 values, as `total += loss.item()` does (structure.py:852)."""
+    a = np.asarray(x, dtype=np.float64)
+    return float(np.cumsum(a)[-1]) if a.size else 0.0
+
+
+def fit(model, train_loader, val_loader, optimizer, num_epochs, progress=None):
+    """The epoch loop of train_model (structure.py:840-868) on the device path.
+    Returns (train_losses, val_losses): per-epoch mean of batch means, Python floats."""
+    binding = AdamBinding(model, optimizer)
+    U, V = model.U.data, model.V.data
+    dev = U.device
+    n, m = U.shape[0], V.shape[0]
+    train = SampleStore.from_loader(train_loader, n, m, dev)
+    val = SampleStore.from_loader(val_loader, n, m, dev)
+    per_epoch_train, per_epoch_val = [], []
+    it = range(num_epochs) if progress is None else progress(range(num_epochs))
+    for _ in it:
+        order, bs = epoch_order(train_loader)           # structure.py:845 iter(train_loader)
+        stream = train.ordered(order)
+        per_epoch_train.append(train_steps(binding, stream, bs))
+        vorder, vbs = epoch_order(val_loader)           # structure.py:861 iter(val_loader)
+        vl, _, _ = eval_batches(U, V, val.ordered(vorder), vbs)
+        per_epoch_val.append(vl)
+    # one device->host transfer for the whole run (the reference syncs every step at 852)
+    tl = [python_float_sum(t.cpu().numpy()) / max(len(t), 1) for t in per_epoch_train]
+    vl = [python_float_sum(t.cpu().numpy()) / max(len(t), 1) for t in per_epoch_val]
+    return tl, vl
+
+
+def evaluate(model, test_loader):
+    """evaluate_model (structure.py:881-921) on the device path → (mean batch BCE, accuracy)."""
+    U, V = model.U.data, model.V.data
+    store = SampleStore.from_loader(test_loader, U.shape[0], V.shape[0], U.device)
+    order, bs = epoch_order(test_loader)
+    loss, corr, _ = eval_batches(U, V, store.ordered(order), bs)
+    total = int(order.numel())
+    lsum = python_float_sum(loss.cpu().numpy())
+    correct = int(corr.sum().item()) if total else 0
+    return lsum / max(len(loss), 1), (correct / total if total > 0 else 0.0)

@@ -1,0 +1,147 @@
+"""Dense reconstruction / alignment metrics on the device path.
+
+The n x m product UV^T is never materialised for the Frobenius / Pearson / slope / alpha metrics:
+libmfcd_hip.so's MFMA pass returns per-row sums and two global sums (include/mfcd.h,
+mfcd_uvt_stats), and everything the reference derives from them is formed here in f64.
+
+Spearman correlations and the singular-value error (structure.py:1011-1031) are SURVEY §8f row N4
+("next"): until they get their own kernels they run as torch ops on the same GPU (sort-based ranks,
+svdvals); they are not part of the hot-path parity claim.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_ws = {}
+
+
+def _workspace(nbytes, device):
+    buf = _ws.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws[device] = buf
+    return buf
+
+
+def uvt_stats(U, V, X, s=1.0):
+    """→ (row_stats f64 [n,8] on device, scal f64 [4] on device); layout in include/mfcd.h."""
+    L = _lib.load()
+    for t, nm in ((U, "U"), (V, "V"), (X, "X")):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise _lib.MfcdError(f"{nm} must be a float32 GPU tensor (no CPU fallback)")
+    U, V, X = U.contiguous(), V.contiguous(), X.contiguous()
+    (n, d), m = U.shape, V.shape[0]
+    if X.shape != (n, m):
+        raise ValueError(f"X must be [{n},{m}], got {tuple(X.shape)}")
+    row_stats = torch.empty((n, 8), dtype=torch.float64, device=U.device)
+    scal = torch.empty(4, dtype=torch.float64, device=U.device)
+    ws = _workspace(L.mfcd_uvt_workspace_bytes(n, m, d), U.device)
+    _lib.check(L.mfcd_uvt_stats(_lib.ptr(U), _lib.ptr(V), _lib.ptr(X), n, m, d, float(s), _lib.ptr(row_stats),
+                                _lib.ptr(scal), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(U.device)))
+    return row_stats, scal
+
+
+def uvt_rows(U, V, row_ids):
+    """Rows `row_ids` of UV^T as a [k, m] fp32 device tensor (structure.py:389-392 without the full GEMM)."""
+    L = _lib.load()
+    U, V = U.contiguous(), V.contiguous()
+    ids = torch.as_tensor(row_ids, dtype=torch.int32).to(U.device).contiguous()
+    k, m = ids.numel(), V.shape[0]
+    out = torch.empty((k, m), dtype=torch.float32, device=U.device)
+    _lib.check(L.mfcd_uvt_rows(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ids), k, U.shape[0], m, U.shape[1], _lib.ptr(out),
+                               _lib.stream_ptr(U.device)))
+    return out
+
+
+def reconstruction_error(U, V, X, s):
+    """compute_reconstruction_error (structure.py:925-955) → float."""
+    _, scal = uvt_stats(U, V, X, s)
+    e2, r2 = scal[:2].cpu().tolist()
+    return float(np.sqrt(e2) / np.sqrt(r2)) if r2 > 0 else float("nan") if e2 == 0 else float("inf")
+
+
+def _rank_rows(M):
+    """Average ranks along dim 1 (what scipy.stats.rankdata gives), on the GPU."""
+    n, m = M.shape
+    srt, idx = torch.sort(M, dim=1, stable=True)
+    base = torch.arange(1, m + 1, device=M.device, dtype=torch.float64).expand(n, m)
+    # ties: average the positions of equal runs
+    new_run = torch.ones_like(srt, dtype=torch.bool)
+    new_run[:, 1:] = srt[:, 1:] != srt[:, :-1]
+    run_id = torch.cumsum(new_run, dim=1) - 1
+    flat = run_id + (torch.arange(n, device=M.device) * m)[:, None]
+    sums = torch.zeros(n * m, dtype=torch.float64, device=M.device).scatter_add_(0, flat.reshape(-1), base.reshape(-1))
+    cnts = torch.zeros(n * m, dtype=torch.float64, device=M.device).scatter_add_(
+        0, flat.reshape(-1), torch.ones(n * m, dtype=torch.float64, device=M.device))
+    avg = (sums / cnts.clamp_min(1))[flat.reshape(-1)].reshape(n, m)
+    ranks = torch.empty_like(avg)
+    ranks.scatter_(1, idx, avg)
+    return ranks
+
+
+def spearman_and_svd(U, V, X_centred_rows_mean, X, alpha, ok_rows, row_block=2048):
+    """N4 ("next") rows on torch-GPU ops: per-row Spearman rho and the singular-value error."""
+    n, m = X.shape
+    rho = torch.empty(n, dtype=torch.float64, device=X.device)
+    vbar = V.mean(dim=0, keepdim=True)
+    for r0 in range(0, n, row_block):
+        r1 = min(n, r0 + row_block)
+        A = U[r0:r1] @ (V - vbar).t()                      # row-centred UV^T block (ranks ignore the shift)
+        ra, rx = _rank_rows(A), _rank_rows(X[r0:r1])
+        ra = ra - ra.mean(1, keepdim=True)
+        rx = rx - rx.mean(1, keepdim=True)
+        rho[r0:r1] = (ra * rx).sum(1) / torch.sqrt((ra * ra).sum(1) * (rx * rx).sum(1))
+    rho = rho.cpu().numpy()
+    scores = [float(r) for r, o in zip(rho, ok_rows) if o and not np.isnan(r)]
+    # singular values: X centred (n x m); UV^T centred has rank <= d -> spectrum from a d x d problem
+    try:
+        Xc = X - X_centred_rows_mean[:, None]
+        s1 = torch.linalg.svdvals(Xc.double())
+        Vc = (V - vbar).double()
+        # sigma(U Vc^T) = sqrt(eig( (U^T U)^{1/2} (Vc^T Vc) (U^T U)^{1/2} )) ; use QR-free form via svdvals of R factors
+        Ru = torch.linalg.qr(U.double(), mode="r").R
+        Rv = torch.linalg.qr(Vc, mode="r").R
+        s2 = torch.linalg.svdvals(Ru @ Rv.t())
+        k = min(len(s1), n, m)
+        s2p = torch.zeros(k, dtype=torch.float64, device=X.device)
+        s2p[: min(k, len(s2))] = s2[: min(k, len(s2))]
+        svd_err = float((torch.linalg.norm(alpha * s2p - s1[:k]) / (torch.linalg.norm(s1[:k]) + 1e-8)).item())
+        failed = False
+    except Exception:  # the reference swallows SVD failures the same way (structure.py:1018-1020)
+        svd_err, failed = 1.0, True
+    return scores, svd_err, failed
+
+
+def alpha_and_norm_ratios(U, V, X):
+    """compute_alpha_and_norm_ratios (structure.py:958-1082) → the same 14-tuple."""
+    row_stats, _ = uvt_stats(U, V, X, 1.0)
+    rs = row_stats.cpu().numpy()
+    n, m = X.shape
+    sac, saa, scc = rs[:, 0], rs[:, 1], rs[:, 2]
+    dot, nu2, nx2 = float(sac.sum()), float(saa.sum()), float(scc.sum())
+    norm_UVT, norm_X = float(np.sqrt(nu2)), float(np.sqrt(nx2))
+    alpha = dot / (norm_UVT ** 2 + 1e-8)                                        # 994
+    norm_ratio = norm_UVT / (norm_X + 1e-8)                                     # 995
+    rec_scaled = float(np.sqrt(max(alpha * alpha * nu2 - 2 * alpha * dot + nx2, 0.0))) / (norm_X + 1e-8)  # 996
+    std_x, std_u = np.sqrt(scc / m), np.sqrt(saa / m)                            # np.std of centred rows
+    ok = (std_x > 1e-8) & (std_u > 1e-8)                                         # 1006, 1027
+    with np.errstate(invalid="ignore", divide="ignore"):
+        corr_all = sac / np.sqrt(saa * scc)
+    correlations = [c for c in corr_all[ok]]                                     # np.float64 like np.corrcoef
+    pearson_mean = float(np.mean(correlations)) if correlations else 0.0
+    xm = torch.from_numpy(rs[:, 4]).to(device=X.device, dtype=torch.float32)
+    spearman_scores, svd_err, failed = spearman_and_svd(U, V, xm, X, alpha, ok)
+    if failed:
+        pearson_mean = 0.0                                                       # structure.py:1019
+    spearman_mean = float(np.mean(spearman_scores)) if spearman_scores else 0.0
+    pearson_std = float(np.std(correlations)) if correlations else 0.0
+    spearman_std = float(np.std(spearman_scores)) if spearman_scores else 0.0
+    sl_ok = (scc > 1e-8) & (std_u > 1e-8)                                        # 1042-1043
+    slopes = [np.float32(v) for v in (sac[sl_ok] / scc[sl_ok])]                  # np.dot of fp32 rows -> np.float32
+    with np.errstate(invalid="ignore", divide="ignore"):
+        a_i = np.where(saa > 1e-8, sac / np.where(saa > 1e-8, saa, 1.0), 0.0)    # 1057-1058
+    alpha_per_row = [np.float32(v) if saa[k] > 1e-8 else 0.0 for k, v in enumerate(a_i)]
+    rec_rows = float(np.sqrt(max(float(np.sum(a_i * a_i * saa - 2 * a_i * sac + scc)), 0.0))) / (norm_X + 1e-8)  # 1064
+    return (alpha, norm_X, norm_ratio, rec_scaled, pearson_mean, pearson_std, spearman_mean, spearman_std,
+            svd_err, slopes, correlations, spearman_scores, rec_rows, alpha_per_row)

@@ -1,0 +1,383 @@
+"""MI355X-native drop-in for the reference module of the same name.
+
+Same function names, argument meaning, return types and `.pkl` layout as
+MayeulCassier/Matrix-Factorization-With-Comparison-Data `structure.py` (cited below as ref:LINE),
+so `Runs.ipynb` / `Plots.ipynb` work unchanged — but the training step, the evaluation pass and the
+dense UV^T metrics run as hand-written gfx950 kernels behind the C-ABI in include/mfcd.h.
+This file is host glue only; it holds no arithmetic of the hot path and has no CPU fallback:
+`device` must name a GPU.
+"""
+import itertools
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader, Dataset
+
+from generation_data import *  # noqa: F401,F403  (ref:17 re-exports every sampler/generator name)
+import generation_data as _gd
+from mfcd import engine as _engine
+from mfcd import metrics as _metrics
+
+try:  # progress bars are cosmetic (ref:840)
+    from tqdm import tqdm as _tqdm
+except Exception:  # pragma: no cover
+    _tqdm = None
+
+
+# ------------------------------------------------------------------------------------------------
+# model (ref:746-795)
+# ------------------------------------------------------------------------------------------------
+class MatrixFactorization(nn.Module):
+    """BTL comparison model: P(u prefers i over j) = sigmoid(U[u] . (V[i] - V[j])).
+
+    Parameters `.U [n_users, d]`, `.V [n_items, d]`, fp32, drawn N(0, 1/d) in this order (ref:770-771).
+    Calling the module evaluates the forward kernel (no autograd graph: training goes through
+    `train_model`, which fuses backward and Adam on the device)."""
+
+    def __init__(self, n_users, n_items, d):
+        super().__init__()
+        scale = torch.sqrt(torch.tensor(d, dtype=torch.float32))
+        self.U = nn.Parameter(torch.randn(n_users, d) / scale)
+        self.V = nn.Parameter(torch.randn(n_items, d) / scale)
+
+    def forward(self, u, i, j):
+        U, V = self.U.data, self.V.data
+        rows = torch.stack([torch.as_tensor(u).reshape(-1).double().cpu(), torch.as_tensor(i).reshape(-1).double().cpu(),
+                            torch.as_tensor(j).reshape(-1).double().cpu(),
+                            torch.zeros(torch.as_tensor(u).numel(), dtype=torch.float64)], 1).numpy()
+        store = _engine.SampleStore(rows, U.shape[0], V.shape[0], U.device)
+        _, _, p = _engine.eval_batches(U, V, store.dev, max(store.N, 1), want_p=True)
+        return p
+
+
+# ------------------------------------------------------------------------------------------------
+# training / evaluation (ref:812-921)
+# ------------------------------------------------------------------------------------------------
+def _need_gpu(device):
+    if torch.device(device).type != "cuda":
+        raise RuntimeError(f"device={device!r}: this build runs the triplet hot path on an MI355X only; "
+                           "pass device='cuda' (there is deliberately no CPU fallback)")
+
+
+def train_model(model, train_loader, val_loader, optimizer, device, num_epochs=100, is_last=False,
+                open_browser=False):
+    """ref:812-878.  Returns (train_losses, val_losses), one Python float per epoch
+    (mean over batches of the batch-mean BCE; the short last batch weighs like any other).
+    `is_last` / `open_browser` only ever fed the reference's disabled TensorBoard block."""
+    _need_gpu(device)
+    model.train()
+    progress = (lambda it: _tqdm(it, desc="Training Progress")) if _tqdm is not None else None
+    out = _engine.fit(model, train_loader, val_loader, optimizer, num_epochs, progress)
+    model.eval()
+    return out
+
+
+def evaluate_model(model, test_loader, device):
+    """ref:881-921 → (mean batch BCE, accuracy of (p > 0.5) against the labels)."""
+    _need_gpu(device)
+    model.eval()
+    return _engine.evaluate(model, test_loader)
+
+
+def compute_reconstruction_error(model, X, s):
+    """ref:925-955 → ||(UV^T - column mean) - sX||_F / ||sX||_F as a float."""
+    return _metrics.reconstruction_error(model.U.data, model.V.data, X, s)
+
+
+def compute_alpha_and_norm_ratios(model, X_init):
+    """ref:958-1082 → the 14-tuple in the reference's order."""
+    return _metrics.alpha_and_norm_ratios(model.U.data, model.V.data, X_init)
+
+
+def compute_ground_truth_metrics(test_loader, X, device):
+    """ref:1085-1127: MSE between sigmoid(X[u,i]-X[u,j]) (no scale) and the labels, per batch, and
+    the accuracy of (diff > 0).  Two-element gather per sample, once per experiment: torch ops on
+    `device`, not a kernel."""
+    rows = torch.from_numpy(_engine.dataset_records(test_loader.dataset)).to(X.device)
+    order, bs = _engine.epoch_order(test_loader)  # same RNG draw as iterating the loader
+    rows = rows[order.to(X.device)]
+    u, i, j = rows[:, 0].long(), rows[:, 1].long(), rows[:, 2].long()
+    z = rows[:, 3].float()
+    diff = X[u, i] - X[u, j]
+    se = (torch.sigmoid(diff) - z) ** 2
+    total, loss_sum, nb = rows.shape[0], 0.0, 0
+    for off in range(0, total, bs):
+        loss_sum += se[off:off + bs].mean().item()
+        nb += 1
+    correct = ((diff > 0).float() == z).sum().item()
+    return loss_sum / max(nb, 1), (correct / total if total > 0 else 0.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# data (ref:465-742)
+# ------------------------------------------------------------------------------------------------
+class BTLPreferenceDataset(Dataset):
+    """ref:465-531.  `.data` is a list of (u, i, j, label) tuples.  Labels are drawn with ONE
+    vectorised torch.bernoulli call over all rows, which consumes the CPU generator exactly like the
+    reference's one-call-per-row loop (same serial kernel, same order)."""
+
+    def __init__(self, triplets, X, scale=1.0, K=1, soft_label=False, train=False):
+        self.X, self.scale, self.soft_label = X, scale, soft_label
+        self.data = self._generate_labels(triplets, K, train=train)
+
+    def _generate_labels(self, triplets, K, train=False):
+        trip = [tuple(int(v) for v in t) for t in triplets]
+        if not trip:
+            return []
+        idx = torch.tensor(trip, dtype=torch.int64)
+        Xc = self.X.detach().to("cpu")
+        score = torch.sigmoid(self.scale * (Xc[idx[:, 0], idx[:, 1]] - Xc[idx[:, 0], idx[:, 2]]))  # ref:509
+        draws = torch.bernoulli(score.repeat_interleave(K)).view(len(trip), K)
+        if self.soft_label and train:                                   # ref:510-513
+            lab = draws.mean(dim=1).tolist()
+            return [(u, i, j, l) for (u, i, j), l in zip(trip, lab)]
+        flat = draws.reshape(-1).tolist()                               # ref:516-518
+        return [trip[r // K] + (flat[r],) for r in range(len(flat))]
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        return self.data[idx]
+
+
+_STRATEGIES = {
+    "random": lambda X, k, ex, **kw: _gd.choose_items_random(X, num_triplets=k, exclude=ex),
+    "proximity": lambda X, k, ex, **kw: _gd.choose_items_by_proximity(X, k, ex),
+    "margin": lambda X, k, ex, **kw: _gd.choose_items_by_margin(X, k, ex),
+    "variance": lambda X, k, ex, **kw: _gd.choose_items_by_variance(X, k, ex),
+    "popularity": lambda X, k, ex, **kw: _gd.choose_items_by_popularity(
+        X, k, ex, method=kw["popularity_method"], alpha=kw["alpha"]),
+    "top_k": lambda X, k, ex, **kw: _gd.choose_items_top_k(X, k, ex),
+    "cluster": lambda X, k, ex, **kw: _gd.choose_items_cluster_based(X, k, ex, n_clusters=kw["n_clusters"]),
+    "user_similarity": lambda X, k, ex, **kw: _gd.choose_items_by_user_similarity(X, k, ex),
+    "svd": lambda X, k, ex, **kw: _gd.choose_items_by_svd_projection(X, k, ex),
+}
+
+
+def get_triplets_from_X(X, num_triplets, strategy="random", exclude=None, popularity_method="zipf", alpha=1.5,
+                        n_clusters=10):
+    """ref:533-588 → set of unique (u, i, j)."""
+    if strategy not in _STRATEGIES:
+        raise ValueError(f"Unknown triplet sampling strategy: {strategy}")
+    found = _STRATEGIES[strategy](X, num_triplets, exclude or set(), popularity_method=popularity_method,
+                                  alpha=alpha, n_clusters=n_clusters)
+    return set(found)
+
+
+_FACTOR_GENERATORS = ("structured", "svd", "correlated", "graph", "social", "temporal", "hierarchical", "gmm")
+
+
+def generate_X(n, m, d, device, generation="base", **kwargs):
+    """ref:590-663 → ground-truth preference matrix [n, m] fp32 on `device`."""
+    if generation == "base":
+        return _gd.generate_embeddings(n, m, d, device=device)
+    if generation == "low_rank":
+        A, B, S = _gd.generate_low_rank_matrix(n, m, d, rank=kwargs.get("rank", d), device=device)
+        return (A * S) @ B.t()
+    if generation == "clustered":
+        return _gd.generate_clustered_matrix_from_embeddings(n, m, d, device=device)
+    if generation in _FACTOR_GENERATORS:
+        A, B = getattr(_gd, f"generate_{generation}_embeddings")(n, m, d, device=device)
+        return A @ B.t()
+    raise ValueError(f"Unknown generation method: {generation}")
+
+
+def split_dataset_from_triplets(X, num_triplets, scale=1.0, K=1, train_ratio=0.8, val_ratio=0.1, batch_size=64,
+                                strategy="random", popularity_method="zipf", alpha=1.5, soft_label=False):
+    """ref:666-742 → (train_loader, val_loader, test_loader)."""
+    triplets = list(get_triplets_from_X(X, num_triplets, strategy=strategy, popularity_method=popularity_method,
+                                        alpha=alpha))
+    if len(triplets) < num_triplets:
+        print(f"⚠️ Only {len(triplets)} triplets generated for strategy: {strategy} (target={num_triplets})")
+    total = len(triplets)
+    n_train, n_val = int(train_ratio * total), int(val_ratio * total)
+    parts = torch.utils.data.random_split(triplets, [n_train, n_val, total - n_train - n_val],
+                                          generator=torch.Generator().manual_seed(42))      # ref:710-713
+    tr, va, te = ([triplets[k] for k in part.indices] for part in parts)
+    min_test = 500                                                                           # ref:721
+    if len(te) * K < min_test:
+        te = te + list(get_triplets_from_X(X, (min_test + K - 1) // K - len(te), strategy=strategy,
+                                           popularity_method=popularity_method, alpha=alpha,
+                                           exclude=set(tr + va + te)))
+    mk = lambda t, train: BTLPreferenceDataset(t, X, scale=scale, K=K, soft_label=soft_label, train=train)  # noqa: E731
+    return (DataLoader(mk(tr, True), batch_size=batch_size, shuffle=True),
+            DataLoader(mk(va, False), batch_size=batch_size, shuffle=False),
+            DataLoader(mk(te, False), batch_size=batch_size, shuffle=False))
+
+
+# ------------------------------------------------------------------------------------------------
+# experiment drivers (ref:81-450, 1154-1269): API / .pkl contract only
+# ------------------------------------------------------------------------------------------------
+_RESULT_KEYS = ("reconstruction_errors", "log_likelihoods", "accuracy", "gt_log_likelihoods", "gt_accuracy",
+                "train_losses", "val_losses", "alpha", "norm_X", "norm_ratio", "reconstruction_error_scaled",
+                "pearson_corr", "pearson_std", "spearman_corr", "spearman_std", "svd_error_scaled", "slopes",
+                "pearson_corr_matrix", "spearman_corr_matrix", "reconstruction_error_scaled_per_row",
+                "alpha_per_row", "sampled_UVT_rows", "sampled_X_rows")
+
+
+def run_experiment(n, m, d, p, s, device, lr, weight_decay, reps=5, num_epochs=100, open_browser=False, K=1,
+                   d1=None, strategy="random", popularity_method="zipf", alpha=1.5, soft_label=False,
+                   generation="base"):
+    """ref:306-450 → dict with the 23 keys of ref:420-444, one list entry per repetition."""
+    res = {k: [] for k in _RESULT_KEYS}
+    for rep in range(reps):
+        X = generate_X(n, m, d, device, generation=generation)
+        loaders = split_dataset_from_triplets(X, int(n * m * p / 2), scale=s, K=K, strategy=strategy,
+                                              popularity_method=popularity_method, alpha=alpha,
+                                              soft_label=soft_label)
+        train_loader, val_loader, test_loader = loaders
+        model = MatrixFactorization(n, m, d).to(device)
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+        t_losses, v_losses = train_model(model, train_loader, val_loader, optimizer, device, num_epochs=num_epochs,
+                                         is_last=(rep == reps - 1), open_browser=open_browser)
+        test_loss, test_acc = evaluate_model(model, test_loader, device)
+        rec_error = compute_reconstruction_error(model, X, s)
+        m14 = compute_alpha_and_norm_ratios(model, X)
+        rows = torch.randperm(X.shape[0])[:2]                                     # ref:390 (global generator)
+        gt_loss, gt_acc = compute_ground_truth_metrics(test_loader, X, device)
+        for key, val in zip(("alpha", "norm_X", "norm_ratio", "reconstruction_error_scaled", "pearson_corr",
+                             "pearson_std", "spearman_corr", "spearman_std", "svd_error_scaled", "slopes",
+                             "pearson_corr_matrix", "spearman_corr_matrix", "reconstruction_error_scaled_per_row",
+                             "alpha_per_row"), m14):
+            res[key].append(val)
+        res["train_losses"].append(t_losses)
+        res["val_losses"].append(v_losses)
+        res["accuracy"].append(test_acc)
+        res["log_likelihoods"].append(-test_loss)
+        res["reconstruction_errors"].append(rec_error)
+        res["gt_log_likelihoods"].append(-gt_loss)
+        res["gt_accuracy"].append(gt_acc)
+        res["sampled_X_rows"].append(X[rows.to(X.device)].cpu().numpy())
+        res["sampled_UVT_rows"].append(_metrics.uvt_rows(model.U.data, model.V.data, rows).cpu().numpy())
+    return res
+
+
+def _to_python(v):
+    if isinstance(v, (np.float32, np.float64)):
+        return float(v)
+    if isinstance(v, np.integer):
+        return int(v)
+    return v
+
+
+def _append_pickle(path, new_items):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    old = []
+    if os.path.exists(path):
+        with open(path, "rb") as f:
+            old = pickle.load(f)
+    old.extend(new_items)
+    with open(path, "wb") as f:
+        pickle.dump(old, f)
+    print(f"✅ Saved {len(new_items)} new experiments to {path}")
+
+
+_SCAN_KEYS = ("n", "m", "d", "p", "lr", "weight_decay", "num_epochs", "reps", "s", "K", "d1", "strategy",
+              "popularity_method", "alpha", "soft_label", "generation")
+
+
+def parameter_scan(n=1000, m=1000, d=2, p=0.5, s=1.0, device='cpu', lr=1e-3, weight_decay=1e-5, num_epochs=30,
+                   reps=1, strategy="random", open_browser=False, linear=False, K=1, d1=None, save_path=None,
+                   save_every=None, popularity_method="zipf", alpha=1.5, soft_label=False, generation="base"):
+    """ref:81-255.  Scalar-or-list hyper-parameters → Cartesian product (default) or synchronised
+    linear scan; each experiment yields {'params': ..., 'results': run_experiment(...)}.  With
+    `save_path` the list is pickled (appending every `save_every` experiments) and, like the
+    reference, the function then returns an empty list (ref:200-202)."""
+    given = dict(n=n, m=m, d=d, p=p, lr=lr, weight_decay=weight_decay, num_epochs=num_epochs, reps=reps, s=s, K=K,
+                 d1=d1, strategy=strategy, popularity_method=popularity_method, alpha=alpha, soft_label=soft_label,
+                 generation=generation)
+    grid, lists, synchronised = _normalise_grid({k: given[k] for k in _SCAN_KEYS})
+    if save_path and os.path.exists(save_path):
+        print(f"🧹 Removing existing file at {save_path}")
+        os.remove(save_path)
+    if not linear:
+        configs = [dict(zip(grid.keys(), combo)) for combo in itertools.product(*grid.values())]
+    elif synchronised:
+        configs = [{k: (v[t] if len(v) > 1 else v[0]) for k, v in grid.items()} for t in range(len(lists[0]))]
+    else:
+        raise ValueError("The linear scan is not possible because the parameters are not synchronized.")
+    pending = []
+    for cfg in configs:
+        print(f"\nRunning experiment with parameters: {cfg}")
+        results = run_experiment(n=cfg["n"], m=cfg["m"], d=cfg["d"], p=cfg["p"], s=cfg["s"], device=device,
+                                 lr=cfg["lr"], weight_decay=cfg["weight_decay"], reps=cfg["reps"],
+                                 num_epochs=cfg["num_epochs"], open_browser=open_browser, K=cfg["K"], d1=cfg["d1"],
+                                 strategy=cfg["strategy"], popularity_method=cfg["popularity_method"],
+                                 alpha=cfg["alpha"], soft_label=cfg["soft_label"], generation=cfg["generation"])
+        pending.append({"params": cfg, "results": results})
+        if save_path and save_every and len(pending) >= save_every:
+            _append_pickle(save_path, pending)
+            pending = []
+    if save_path and pending:
+        _append_pickle(save_path, pending)
+        pending = []
+    return pending
+
+
+def print_return_structure_types(obj, prefix="root"):
+    """ref:258-302: debugging aid that prints the type tree of a nested result object."""
+    if isinstance(obj, dict):
+        for key, val in obj.items():
+            print_return_structure_types(val, f"{prefix}.{key}")
+    elif isinstance(obj, (list, tuple)):
+        kinds = {type(e).__name__ for e in obj}
+        inner = "empty" if not obj else (kinds.pop() if len(kinds) == 1 else "mixed")
+        print(f"{prefix}: {type(obj).__name__}[{inner}]")
+    elif isinstance(obj, torch.Tensor):
+        print(f"{prefix}: torch.Tensor")
+    else:
+        print(f"{prefix}: {type(obj).__name__}")
+
+
+def _normalise_grid(given):
+    """Scalar-or-list kwargs → ({name: list}, lists_that_were_lists); NumPy scalars become Python ones (ref:128-148)."""
+    grid = {}
+    for key, v in given.items():
+        if isinstance(v, np.ndarray):
+            v = list(v)
+        elif isinstance(v, list):
+            v = [_to_python(x) for x in v]
+        else:
+            v = _to_python(v)
+        grid[key] = v
+    lists = [v for v in grid.values() if isinstance(v, list)]
+    synchronised = len(lists) <= 1 or all(len(v) == len(lists[0]) for v in lists)
+    grid = {k: (v if isinstance(v, (list, tuple)) else [v]) for k, v in grid.items()}
+    return grid, lists, synchronised
+
+
+def evaluate_ground_truth(n, m, p, d, s, device, K, reps=1, strategy="random", popularity_method="zipf", alpha=1.5,
+                          soft_label=False, generation="base"):
+    """ref:1154-1200 → (losses, accuracies) of the ground-truth matrix itself, one entry per repetition."""
+    losses, accuracies = [], []
+    for _ in range(reps):
+        X = generate_X(n, m, d, device, generation=generation)
+        _, _, test_loader = split_dataset_from_triplets(X, int(n * m * p / 2), scale=s, K=K, strategy=strategy,
+                                                        popularity_method=popularity_method, alpha=alpha,
+                                                        soft_label=soft_label)
+        gt_loss, gt_acc = compute_ground_truth_metrics(test_loader, X, device)
+        losses.append(gt_loss)
+        accuracies.append(gt_acc)
+    return losses, accuracies
+
+
+def parameter_scan_ground_truth(n, m, p, d, s, device, K, linear=False, reps=1, strategy="random",
+                                popularity_method="zipf", alpha=1.5, soft_label=False, generation="base"):
+    """ref:1203-1269 → [{'params': ..., 'results': {'gt_loss': [...], 'gt_accuracy': [...]}}, ...].
+    A linear scan over unsynchronised lists silently becomes a Cartesian scan, as in the reference."""
+    grid, lists, synchronised = _normalise_grid(dict(n=n, m=m, p=p, d=d, s=s, K=K, strategy=strategy,
+                                                     popularity_method=popularity_method, alpha=alpha,
+                                                     soft_label=soft_label, generation=generation))
+    if linear and synchronised:
+        configs = [{k: (v[t] if len(v) > 1 else v[0]) for k, v in grid.items()} for t in range(len(lists[0]))]
+    else:
+        configs = [dict(zip(grid.keys(), combo)) for combo in itertools.product(*grid.values())]
+    out = []
+    for cfg in (_tqdm(configs, desc="Training Progress") if _tqdm is not None else configs):
+        gt_loss, gt_accuracy = evaluate_ground_truth(**cfg, device=device, reps=reps)
+        out.append({"params": cfg, "results": {"gt_loss": gt_loss, "gt_accuracy": gt_accuracy}})
+    return out

@@ -1,0 +1,296 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against
+(a) golden vectors from the unmodified reference and (b) the CPU oracle on the same seeded inputs.
+
+Stated fp32 tolerances (the GPU sums a d-term dot product in wave-shuffle order, ATen in SIMD order,
+and hipcc contracts a*b+c into FMA; everything else is the same arithmetic):
+  sigmoid outputs / losses      rtol 2e-5, atol 2e-7
+  parameters after k steps      atol 2e-6 (k <= 5 epochs of C1), moments rtol 1e-3
+  epoch losses                  atol 2e-6
+  dense metrics                 atol 1e-4 (the north-star bound), typically < 1e-6
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import E2ES, KATS, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-5, 2e-7
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from mfcd import _lib
+    _lib.load()  # fail loudly if the HIP library is not built
+    return torch.device("cuda:0")
+
+
+def _model_from(U0, V0, dev, lr, wd):
+    import structure as S
+    n, d = U0.shape
+    model = S.MatrixFactorization(n, V0.shape[0], d)
+    with torch.no_grad():
+        model.U.copy_(torch.from_numpy(U0))
+        model.V.copy_(torch.from_numpy(V0))
+    model = model.to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+    return model, opt
+
+
+def _records(u, i, j, z, n, m, dev):
+    from mfcd.engine import SampleStore
+    rows = np.stack([np.asarray(u, np.float64), np.asarray(i, np.float64), np.asarray(j, np.float64),
+                     np.asarray(z, np.float64)], 1)
+    return SampleStore(rows, n, m, dev)
+
+
+class ListDataset(torch.utils.data.Dataset):
+    def __init__(self, rows):
+        self.data = [(int(r[0]), int(r[1]), int(r[2]), float(r[3])) for r in rows]
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, k):
+        return self.data[k]
+
+
+# --------------------------------------------------------------------------------------------------
+# (a) golden vectors
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", KATS)
+def test_kat_steps_match_reference(dev, name):
+    from mfcd import engine
+    g = load_golden(name)
+    lr, wd = float(g["lr"]), float(g["wd"])
+    model, opt = _model_from(g["U0"], g["V0"], dev, lr, wd)
+    bind = engine.AdamBinding(model, opt)
+    n, m = g["U0"].shape[0], g["V0"].shape[0]
+    for k in range(int(g["n_steps"])):
+        st = _records(g[f"u{k}"], g[f"i{k}"], g[f"j{k}"], g[f"z{k}"], n, m, dev)
+        _, _, p = engine.eval_batches(model.U.data, model.V.data, st.dev, st.N, want_p=True)
+        np.testing.assert_allclose(p.cpu().numpy(), g[f"p{k}"], rtol=RTOL, atol=ATOL)
+        loss = engine.train_steps(bind, st.dev, st.N)
+        assert loss.numel() == 1
+        ref_loss = float(g[f"loss{k}"])
+        assert abs(float(loss[0]) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+        su, sv = opt.state[model.U], opt.state[model.V]
+        np.testing.assert_allclose(model.U.data.cpu().numpy(), g[f"U{k + 1}"], rtol=1e-6, atol=2e-7)
+        np.testing.assert_allclose(model.V.data.cpu().numpy(), g[f"V{k + 1}"], rtol=1e-6, atol=2e-7)
+        np.testing.assert_allclose(su["exp_avg"].cpu().numpy(), g[f"mU{k + 1}"], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(sv["exp_avg"].cpu().numpy(), g[f"mV{k + 1}"], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(su["exp_avg_sq"].cpu().numpy(), g[f"vU{k + 1}"], rtol=2e-4, atol=1e-13)
+        np.testing.assert_allclose(sv["exp_avg_sq"].cpu().numpy(), g[f"vV{k + 1}"], rtol=2e-4, atol=1e-13)
+        assert float(su["step"]) == k + 1 == float(sv["step"])
+
+
+def test_saturated_terms_and_zero_gradient(dev):
+    """p rounds to 0/1 -> loss term exactly 100 and zero sparse gradient (weight decay only)."""
+    from mfcd import engine
+    g = load_golden("kat_saturated_d8.npz")
+    model, opt = _model_from(g["U0"], g["V0"], dev, float(g["lr"]), float(g["wd"]))
+    st = _records(g["u0"], g["i0"], g["j0"], g["z0"], 24, 24, dev)
+    _, _, p = engine.eval_batches(model.U.data, model.V.data, st.dev, st.N, want_p=True)
+    p = p.cpu().numpy()
+    sat = (g["p0"] == 0.0) | (g["p0"] == 1.0)
+    assert sat.sum() >= 5
+    np.testing.assert_array_equal(p[sat], g["p0"][sat])
+
+
+@pytest.mark.parametrize("name", E2ES)
+def test_e2e_train_eval_metrics_match_reference(dev, name):
+    """train_model / evaluate_model / metric functions of the drop-in module on the reference's own data."""
+    import structure as S
+    g = load_golden(name)
+    lr, wd, E, s = float(g["lr"]), float(g["wd"]), int(g["epochs"]), float(g["s"])
+    model, opt = _model_from(g["U0"], g["V0"], dev, lr, wd)
+    mk = lambda rows, sh: torch.utils.data.DataLoader(ListDataset(rows), batch_size=64, shuffle=sh)  # noqa: E731
+    train, val, test = mk(g["train_data"], True), mk(g["val_data"], False), mk(g["test_data"], False)
+    torch.set_rng_state(torch.from_numpy(g["rng_state_before_train"]))
+    tl, vl = S.train_model(model, train, val, opt, "cuda", num_epochs=E)
+    assert bool((torch.get_rng_state().numpy() == g["rng_state_after_train"]).all()), "RNG stream diverged"
+    np.testing.assert_allclose(tl, g["train_losses"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(vl, g["val_losses"], rtol=0, atol=2e-6)
+    assert isinstance(tl, list) and isinstance(tl[0], float) and len(tl) == E
+    U, V = model.U.data.cpu().numpy(), model.V.data.cpu().numpy()
+    np.testing.assert_allclose(U, g["U_final"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(V, g["V_final"], rtol=0, atol=2e-6)
+    # north-star: UV^T reconstruction MSE vs the reference's factors
+    mse = float(np.mean((U @ V.T - g["U_final"] @ g["V_final"].T) ** 2))
+    assert mse < 1e-10
+    assert float(opt.state[model.U]["step"]) == float(g["adam_step"])
+    te_loss, te_acc = S.evaluate_model(model, test, "cuda")
+    assert te_loss == pytest.approx(float(g["test_loss"]), abs=2e-6)
+    assert te_acc == pytest.approx(float(g["test_acc"]), abs=1e-12)
+    X = torch.from_numpy(g["X"]).to(dev)
+    assert S.compute_reconstruction_error(model, X, s) == pytest.approx(float(g["rec_error"]), abs=1e-5)
+    res = S.compute_alpha_and_norm_ratios(model, X)
+    names = ["alpha", "norm_X", "norm_ratio", "rec_scaled", "pearson_mean", "pearson_std", "spearman_mean",
+             "spearman_std", "svd_err", "slopes", "correlations", "spearman_scores", "rec_scaled_per_row",
+             "alpha_per_row"]
+    assert len(res) == 14
+    for nm, v in zip(names, res):
+        ref = g["m14_" + nm]
+        v = np.asarray(v, dtype=np.float64)
+        assert v.shape == ref.shape, nm
+        scale = max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0)
+        np.testing.assert_allclose(v, ref, rtol=0, atol=1e-4 * scale, err_msg=nm)
+    gl, ga = S.compute_ground_truth_metrics(test, X, "cuda")
+    assert gl == pytest.approx(float(g["gt_loss"]), abs=1e-6)
+    assert ga == pytest.approx(float(g["gt_acc"]), abs=1e-12)
+    from mfcd import metrics
+    rows = metrics.uvt_rows(model.U.data, model.V.data, g["sampled_idx"]).cpu().numpy()
+    np.testing.assert_allclose(rows, (U @ V.T)[g["sampled_idx"]], rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------------
+# (b) oracle on seeded inputs, including BASELINE's C2 size, and size-independent properties
+# --------------------------------------------------------------------------------------------------
+def _synthetic(n, m, d, N, seed, soft=False):
+    rng = np.random.default_rng(seed)
+    U0 = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    V0 = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+    u, i = rng.integers(0, n, N), rng.integers(0, m, N)
+    j = (i + 1 + rng.integers(0, max(m - 1, 1), N)) % m
+    z = rng.integers(0, 5, N) / 4.0 if soft else rng.integers(0, 2, N).astype(np.float64)
+    return U0, V0, u, i, j, z
+
+
+@pytest.mark.parametrize("n,m,d,N,B,soft", [
+    (4096, 4096, 64, 67108, 64, False),   # C2 of BASELINE.json: one full epoch, 1049 steps, last batch 36
+    (300, 200, 128, 3000, 64, True),
+    (1000, 1000, 2, 5000, 64, False),     # notebook default d=2
+    (64, 64, 5, 999, 64, True),           # odd d -> scalar path
+    (2, 3, 8, 640, 64, False),            # every batch hits every row many times
+    (500, 400, 16, 2000, 200, False),     # B > 64
+    (128, 96, 256, 130, 1, False),        # B = 1
+    (2048, 1024, 32, 4096, 4096, False),  # one huge batch
+])
+def test_train_epoch_matches_oracle(dev, orc, n, m, d, N, B, soft):
+    from mfcd import engine
+    from oracle import oracle as O
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=n + d + N, soft=soft)
+    lr, wd = 1e-3, 1e-5
+    model, opt = _model_from(U0, V0, dev, lr, wd)
+    bind = engine.AdamBinding(model, opt)
+    st = _records(u, i, j, z, n, m, dev)
+    loss = engine.train_steps(bind, st.dev, B).cpu().numpy()
+    ref = O.new_state(U0, V0)
+    ref_loss = orc.train_steps(ref, u, i, j, z, B, 0, lr=lr, wd=wd, threads=4)
+    np.testing.assert_allclose(loss, ref_loss, rtol=2e-5, atol=2e-6)
+    nsteps = len(ref_loss)
+    tol = 2e-6 + 2e-8 * nsteps
+    np.testing.assert_allclose(model.U.data.cpu().numpy(), ref["U"], rtol=0, atol=tol)
+    np.testing.assert_allclose(model.V.data.cpu().numpy(), ref["V"], rtol=0, atol=tol)
+    np.testing.assert_allclose(opt.state[model.U]["exp_avg"].cpu().numpy(), ref["mU"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(opt.state[model.V]["exp_avg_sq"].cpu().numpy(), ref["vV"], rtol=2e-3, atol=1e-12)
+    vl, vc, vp = engine.eval_batches(model.U.data, model.V.data, st.dev, B, want_p=True)
+    rl, rc, rp = orc.eval_batches(model.U.data.cpu().numpy(), model.V.data.cpu().numpy(), u, i, j, z, B)
+    np.testing.assert_allclose(vp.cpu().numpy(), rp, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(vl.cpu().numpy(), rl, rtol=2e-5, atol=2e-6)
+    # hard labels: counts agree except where p sits within rounding of 0.5
+    near = np.abs(rp - 0.5) < 1e-6
+    assert abs(int(vc.sum()) - int(rc.sum())) <= int(near.sum())
+
+
+def test_properties_at_c2_size(dev):
+    """Size-independent properties at BASELINE C2: run-to-run bit reproducibility, call-splitting
+    invariance (k steps in one call == the same steps over two calls), lr=0 & wd=0 leaves U,V untouched."""
+    from mfcd import engine
+    n = m = 4096
+    d, N, B = 64, 64 * 300 + 17, 64
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=7)
+    st = _records(u, i, j, z, n, m, dev)
+
+    def run(splits):
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        bind = engine.AdamBinding(model, opt)
+        losses = [engine.train_steps(bind, st.dev[a:b], B).clone() for a, b in splits]
+        return model.U.data.clone(), model.V.data.clone(), torch.cat(losses), opt.state[model.U]["exp_avg_sq"].clone()
+
+    a = run([(0, N)])
+    b = run([(0, N)])
+    c = run([(0, 64 * 101), (64 * 101, N)])  # odd number of steps in the first call exercises the ping-pong copy
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), "two identical runs differ"
+    for x, y in zip(a, c):
+        assert torch.equal(x, y), "splitting the call changed the result"
+    model, opt = _model_from(U0, V0, dev, 0.0, 0.0)
+    bind = engine.AdamBinding(model, opt)
+    engine.train_steps(bind, st.dev[:6400], B)
+    assert torch.equal(model.U.data.cpu(), torch.from_numpy(U0)) and torch.equal(model.V.data.cpu(), torch.from_numpy(V0))
+    assert bind.step == 100
+
+
+def test_untouched_rows_move_by_weight_decay_only(dev, orc):
+    """Dense Adam is not optional (SURVEY §7): rows outside the batch still move through wd*p."""
+    from mfcd import engine
+    n = m = 512
+    d = 64
+    U0, V0, *_ = _synthetic(n, m, d, 1, seed=3)
+    model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+    bind = engine.AdamBinding(model, opt)
+    st = _records([5], [7], [9], [1.0], n, m, dev)
+    engine.train_steps(bind, st.dev, 64)
+    dU = np.abs(model.U.data.cpu().numpy() - U0)
+    untouched = np.delete(dU, 5, axis=0)
+    assert untouched[np.abs(np.delete(U0, 5, axis=0)) > 0.05].min() > 9e-4  # ~lr on the first step
+    assert untouched.max() < 1.1e-3
+
+
+def test_empty_and_error_paths(dev):
+    from mfcd import _lib, engine
+    import structure as S
+    U0, V0, u, i, j, z = _synthetic(32, 32, 8, 10, seed=1)
+    model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+    bind = engine.AdamBinding(model, opt)
+    empty = _records([], [], [], [], 32, 32, dev)
+    out = engine.train_steps(bind, empty.dev, 64)
+    assert out.numel() == 0 and bind.step == 0
+    assert torch.equal(model.U.data.cpu(), torch.from_numpy(U0))
+    with pytest.raises(IndexError):
+        _records([32], [0], [1], [1.0], 32, 32, dev)
+    with pytest.raises(RuntimeError):  # no CPU fallback
+        S.train_model(model, None, None, opt, "cpu", num_epochs=1)
+    cpu_model = S.MatrixFactorization(8, 8, 4)
+    cpu_opt = torch.optim.Adam(cpu_model.parameters())
+    with pytest.raises(_lib.MfcdError):
+        engine.AdamBinding(cpu_model, cpu_opt)
+    with pytest.raises(NotImplementedError):
+        engine.AdamBinding(model, torch.optim.SGD(model.parameters(), lr=0.1))
+    L = _lib.load()
+    assert L.mfcd_train_steps(None, None, None, None, None, None, None, 1, 64, 0, 4, 4, 4, 1e-3, .9, .999, 1e-8, 0.,
+                              None, None, 0, None) == -1
+    assert L.mfcd_error_string(-2).decode().startswith("mfcd: workspace")
+
+
+@pytest.mark.parametrize("n,m,d", [(4096, 4096, 64), (1000, 777, 8), (300, 5000, 128), (257, 95, 2), (96, 64, 256),
+                                   (130, 70, 24)])
+def test_uvt_stats_match_oracle(dev, orc, n, m, d):
+    from mfcd import metrics
+    rng = np.random.default_rng(n + m + d)
+    U = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    V = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    Bm = rng.standard_normal((m, d)).astype(np.float32)
+    X = (A @ Bm.T / np.sqrt(d) * 0.5 + 0.1).astype(np.float32)
+    s = 1.7
+    rs, scal = metrics.uvt_stats(torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev), torch.from_numpy(X).to(dev), s)
+    rs, scal = rs.cpu().numpy(), scal.cpu().numpy()
+    if n * m <= 1 << 21:
+        ref_rs, err2, ref2 = orc.uvt_stats(U, V, X, s)
+    else:  # f64 numpy statement of the same sums for the large case
+        G = U.astype(np.float64) @ V.astype(np.float64).T
+        Xd = X.astype(np.float64)
+        a = G - G.mean(1, keepdims=True)
+        c = Xd - Xd.mean(1, keepdims=True)
+        ref_rs = np.stack([(a * c).sum(1), (a * a).sum(1), (c * c).sum(1)], 1)
+        err2 = float((((G - G.mean(0, keepdims=True)) - s * Xd) ** 2).sum())
+        ref2 = float(((s * Xd) ** 2).sum())
+    for col in range(3):
+        scale = np.abs(ref_rs[:, col]).max()
+        np.testing.assert_allclose(rs[:, col], ref_rs[:, col], rtol=0, atol=2e-5 * scale)
+    assert scal[0] == pytest.approx(err2, rel=2e-5)
+    assert scal[1] == pytest.approx(ref2, rel=2e-5)

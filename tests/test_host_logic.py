@@ -1,0 +1,192 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/mfcd.h declares, the host data
+pipeline consumes torch/numpy RNG exactly like the reference (checked against golden fixtures), and
+the drop-in module keeps the reference's names and signatures."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG, ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from mfcd import _lib
+    header = open(os.path.join(ROOT, "include", "mfcd.h")).read()
+    declared = set(re.findall(r"\b(mfcd_[a-z_0-9]+)\s*\(", header))
+    declared.discard("mfcd_sample")
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.load()  # binds each symbol; AttributeError if one is missing
+    assert L.mfcd_abi_version() == 1
+    assert L.mfcd_error_string(0).decode() == "success"
+    assert L.mfcd_error_string(-1).decode().startswith("mfcd:")
+    # pure host helpers may be called without a GPU
+    assert L.mfcd_train_workspace_bytes(1000, 64, 16, 16, 8) >= 2 * 16 * 8 * 4 + 4000
+    assert L.mfcd_uvt_workspace_bytes(100, 100, 8) > 0
+
+
+def test_missing_library_is_loud(monkeypatch):
+    from mfcd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(PKG, "does_not_exist.so"))
+    with pytest.raises(_lib.MfcdError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    import structure as S
+    from mfcd import _lib, engine
+    model = S.MatrixFactorization(8, 8, 4)
+    opt = torch.optim.Adam(model.parameters())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        S.train_model(model, None, None, opt, "cpu", num_epochs=1)
+    with pytest.raises(_lib.MfcdError):
+        engine.AdamBinding(model, opt)
+    with pytest.raises(_lib.MfcdError):
+        engine.eval_batches(model.U.data, model.V.data, torch.zeros((0, 4), dtype=torch.int32), 64)
+
+
+@pytest.mark.parametrize("name,seed", [("e2e_c1.npz", 0), ("e2e_soft_k3.npz", 1), ("e2e_hard_k2_d16.npz", 2)])
+def test_data_pipeline_is_rng_identical_to_reference(name, seed):
+    """generate_X -> split_dataset_from_triplets -> model init -> per-epoch order, all bit-equal to what the
+    reference produced from the same seeds (fixtures from oracle/make_golden.py)."""
+    import structure as S
+    from mfcd.batching import epoch_order
+    g = load_golden(name)
+    n, m, d, K = int(g["n"]), int(g["m"]), int(g["d"]), int(g["K"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    X = S.generate_X(n, m, d, "cpu")
+    np.testing.assert_allclose(X.numpy(), g["X"], rtol=0, atol=1e-6)
+    X = torch.from_numpy(g["X"])  # continue from the reference's X so later comparisons are exact
+    loaders = S.split_dataset_from_triplets(X, int(n * m * float(g["p"]) / 2), scale=float(g["s"]), K=K,
+                                            soft_label=bool(g["soft_label"]))
+    for nm, ld in zip(("train", "val", "test"), loaders):
+        np.testing.assert_array_equal(np.asarray(ld.dataset.data, dtype=np.float64), g[nm + "_data"])
+    model = S.MatrixFactorization(n, m, d)
+    np.testing.assert_array_equal(model.U.detach().numpy(), g["U0"])
+    np.testing.assert_array_equal(model.V.detach().numpy(), g["V0"])
+    np.testing.assert_array_equal(torch.get_rng_state().numpy(), g["rng_state_before_train"])
+    train, val, _ = loaders
+    rows = np.asarray(train.dataset.data, dtype=np.float64)
+    for e in range(int(g["epochs"])):
+        order, bs = epoch_order(train)
+        assert bs == 64
+        np.testing.assert_array_equal(rows[order.numpy()], g["epoch_stream"][e])
+        epoch_order(val)
+    np.testing.assert_array_equal(torch.get_rng_state().numpy(), g["rng_state_after_train"])
+
+
+def test_epoch_order_equals_dataloader_iteration():
+    """epoch_order must visit samples exactly as iterating the DataLoader does, for both samplers."""
+    from mfcd.batching import epoch_order
+    data = [(k, k + 1, k + 2, float(k % 2)) for k in range(203)]
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(data)
+
+        def __getitem__(self, k):
+            return data[k]
+    for shuffle, drop_last in ((True, False), (False, False), (True, True)):
+        ld = torch.utils.data.DataLoader(DS(), batch_size=64, shuffle=shuffle, drop_last=drop_last)
+        torch.manual_seed(5)
+        seen = torch.cat([b[0] for b in ld]).tolist()
+        after_iter = torch.get_rng_state()
+        torch.manual_seed(5)
+        order, bs = epoch_order(ld)
+        assert order.tolist() == seen and bs == 64
+        assert torch.equal(torch.get_rng_state(), after_iter)
+
+
+def test_pack_records_layout_and_bounds():
+    from mfcd.batching import pack_records
+    rec = pack_records([[1, 2, 3, 0.25], [0, 5, 4, 1.0]], n=2, m=6)
+    assert rec.dtype == np.int32 and rec.shape == (2, 4) and rec.flags.c_contiguous and rec.itemsize * 4 == 16
+    assert rec[0, :3].tolist() == [1, 2, 3] and rec[:, 3].view(np.float32).tolist() == [0.25, 1.0]
+    assert pack_records([[-1, -1, 0, 0.0]], n=2, m=6)[0, :3].tolist() == [1, 5, 0]  # Python-style negatives
+    with pytest.raises(IndexError):
+        pack_records([[2, 0, 1, 0.0]], n=2, m=6)
+    with pytest.raises(IndexError):
+        pack_records([[0, 6, 1, 0.0]], n=2, m=6)
+    assert pack_records(np.zeros((0, 4)), 2, 2).shape == (0, 4)
+
+
+REFERENCE_SIGNATURES = {
+    # name: parameter list of the reference (structure.py:81-85, 306, 476, 533-534, 590, 666-669, 766, 812, 881, 925,
+    # 958, 1085, 1154, 1203)
+    "parameter_scan": ["n", "m", "d", "p", "s", "device", "lr", "weight_decay", "num_epochs", "reps", "strategy",
+                       "open_browser", "linear", "K", "d1", "save_path", "save_every", "popularity_method", "alpha",
+                       "soft_label", "generation"],
+    "run_experiment": ["n", "m", "d", "p", "s", "device", "lr", "weight_decay", "reps", "num_epochs", "open_browser",
+                       "K", "d1", "strategy", "popularity_method", "alpha", "soft_label", "generation"],
+    "get_triplets_from_X": ["X", "num_triplets", "strategy", "exclude", "popularity_method", "alpha", "n_clusters"],
+    "generate_X": ["n", "m", "d", "device", "generation", "kwargs"],
+    "split_dataset_from_triplets": ["X", "num_triplets", "scale", "K", "train_ratio", "val_ratio", "batch_size",
+                                    "strategy", "popularity_method", "alpha", "soft_label"],
+    "train_model": ["model", "train_loader", "val_loader", "optimizer", "device", "num_epochs", "is_last",
+                    "open_browser"],
+    "evaluate_model": ["model", "test_loader", "device"],
+    "compute_reconstruction_error": ["model", "X", "s"],
+    "compute_alpha_and_norm_ratios": ["model", "X_init"],
+    "compute_ground_truth_metrics": ["test_loader", "X", "device"],
+    "evaluate_ground_truth": ["n", "m", "p", "d", "s", "device", "K", "reps", "strategy", "popularity_method",
+                              "alpha", "soft_label", "generation"],
+    "parameter_scan_ground_truth": ["n", "m", "p", "d", "s", "device", "K", "linear", "reps", "strategy",
+                                    "popularity_method", "alpha", "soft_label", "generation"],
+    "print_return_structure_types": ["obj", "prefix"],
+}
+
+
+def test_drop_in_module_keeps_reference_signatures():
+    import structure as S
+    for name, params in REFERENCE_SIGNATURES.items():
+        assert list(inspect.signature(getattr(S, name)).parameters) == params, name
+    assert list(inspect.signature(S.MatrixFactorization.__init__).parameters) == ["self", "n_users", "n_items", "d"]
+    assert list(inspect.signature(S.BTLPreferenceDataset.__init__).parameters) == [
+        "self", "triplets", "X", "scale", "K", "soft_label", "train"]
+    d = inspect.signature(S.parameter_scan).parameters
+    assert (d["n"].default, d["d"].default, d["lr"].default, d["weight_decay"].default, d["num_epochs"].default) == \
+        (1000, 2, 1e-3, 1e-5, 30)
+    assert inspect.signature(S.split_dataset_from_triplets).parameters["batch_size"].default == 64
+    for name in ("choose_items_random", "choose_items_by_margin", "choose_items_by_popularity", "choose_items_top_k",
+                 "choose_items_by_proximity", "choose_items_by_variance", "choose_items_by_svd_projection",
+                 "choose_items_cluster_based", "choose_items_by_user_similarity", "generate_embeddings",
+                 "generate_low_rank_matrix", "generate_gmm_embeddings"):
+        assert callable(getattr(S, name)), name  # `from generation_data import *` re-export (structure.py:17)
+    with pytest.raises(ValueError):
+        S.get_triplets_from_X(torch.zeros(4, 4), 1, strategy="nope")
+    with pytest.raises(ValueError):
+        S.generate_X(4, 4, 2, "cpu", generation="nope")
+    with pytest.raises(ValueError):
+        S.parameter_scan(n=[4, 5], m=[4, 5, 6], linear=True)
+
+
+def test_samplers_respect_uniqueness_and_exclude():
+    import structure as S
+    torch.manual_seed(0)
+    np.random.seed(0)
+    X = torch.randn(30, 20)
+    for strategy in ("random", "popularity", "top_k", "proximity", "variance", "margin"):
+        first = S.get_triplets_from_X(X, 40, strategy=strategy)
+        assert isinstance(first, set) and len(first) <= 40
+        assert all(0 <= u < 30 and 0 <= i < 20 and 0 <= j < 20 and i != j for u, i, j in first), strategy
+        if strategy != "margin":
+            assert len(first) == 40
+            more = S.get_triplets_from_X(X, 20, strategy=strategy, exclude=first)
+            assert not (more & first), strategy
+
+
+def test_labels_follow_btl_statistics():
+    import structure as S
+    torch.manual_seed(1)
+    X = torch.tensor([[2.0, -2.0], [0.0, 0.0]])
+    ds = S.BTLPreferenceDataset([(0, 0, 1), (1, 0, 1)] * 2000, X, scale=1.0, K=1)
+    lab = np.array([r[3] for r in ds.data]).reshape(-1, 2)
+    assert abs(lab[:, 0].mean() - 1 / (1 + np.exp(-4.0))) < 0.02 and abs(lab[:, 1].mean() - 0.5) < 0.03
+    soft = S.BTLPreferenceDataset([(0, 0, 1)] * 50, X, K=4, soft_label=True, train=True)
+    assert len(soft) == 50 and all(r[3] in (0.0, 0.25, 0.5, 0.75, 1.0) for r in soft.data)
+    hard = S.BTLPreferenceDataset([(0, 0, 1)] * 50, X, K=4, soft_label=True, train=False)
+    assert len(hard) == 200 and all(r[3] in (0.0, 1.0) for r in hard.data)
