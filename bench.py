@@ -22,6 +22,8 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+os.environ.setdefault("OMP_NUM_THREADS", "4")  # the reference's own setting (structure.py:3)
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -100,7 +100,9 @@ class SampleStore:
         if order.numel() == self.N and bool((order[:1] == 0).all()) and order.numel() > 1 and \
                 bool((order[1:] - order[:-1] == 1).all()):
             return self.dev
-        return self.dev.index_select(0, order.to(self.device, non_blocking=True))
+        # pinned staging buffer -> the upload is asynchronous and does not drain the stream (a pageable
+        # H2D copy would block the host until every queued step kernel has finished)
+        return self.dev.index_select(0, order.pin_memory().to(self.device, non_blocking=True))
 
 
 class Workspace:

@@ -11,6 +11,8 @@ import itertools
 import os
 import pickle
 
+os.environ.setdefault("OMP_NUM_THREADS", "4")  # the reference pins this at import (ref:3); host work here is tiny
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -20,6 +22,9 @@ from generation_data import *  # noqa: F401,F403  (ref:17 re-exports every sampl
 import generation_data as _gd
 from mfcd import engine as _engine
 from mfcd import metrics as _metrics
+
+if torch.get_num_threads() > 16:  # imported after torch: keep the host-side pool small (GPU boxes expose 100s of cores)
+    torch.set_num_threads(4)
 
 try:  # progress bars are cosmetic (ref:840)
     from tqdm import tqdm as _tqdm
