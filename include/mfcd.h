@@ -69,8 +69,23 @@ int mfcd_eval_batches(const float *U, const float *V, const mfcd_sample *samples
                       int n, int m, int d, float *loss_per_batch, int32_t *correct_per_batch,
                       float *p_out, void *stream);
 
-/* Bytes of device workspace mfcd_train_steps needs for these sizes. */
+/*
+ * Bytes of device workspace mfcd_train_steps needs for these sizes.  The first 4 bytes of the
+ * workspace are an int32 status word written by the call: 0 = ok, 1 = a bounded in-kernel wait
+ * expired (resident form only; U, V, m, v are then undefined).  Read it after the stream has drained.
+ */
 size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d);
+
+/*
+ * Which form of the fused step mfcd_train_steps uses (process-wide):
+ *   0 auto (default)  resident when it applies, else streaming
+ *   1 streaming       one launch per optimiser step, state streamed through HBM (any size, any d)
+ *   2 resident        one persistent launch per call, p/m/v held in registers, rows exchanged through
+ *                     tagged 8-byte granules; needs d a power of two <= 256 and 12*(n+m)*d bytes of
+ *                     state to fit the register files; MFCD_EINVAL from mfcd_train_steps otherwise
+ * Both forms compute the same step (same summation order per row); results agree to fp32 rounding.
+ */
+int mfcd_set_train_path(int mode);
 
 /*
  * Runs ceil(N/B) sequential optimiser steps on the device, consuming `samples` in order in

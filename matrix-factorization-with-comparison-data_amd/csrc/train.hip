@@ -15,20 +15,17 @@
 //   HBM traffic per element is the 24-byte minimum: read p,m,v, write p,m,v.
 //
 // Roofline: HBM-bound streaming; algorithmic bytes per step = 24*(n+m)*d + 12*B*d + 16*B.
+#include <mutex>
 #include <vector>
 
 #include "common.h"
+#include "train_common.h"
 
 namespace {
 
 struct AdamConst {
-    float w1;   // 1 - beta1
-    float b2;   // beta2
-    float w2;   // 1 - beta2
-    float eps;
-    float wd;
-    float neg_step_size;  // -(lr / (1 - beta1^t))   (f64 on the host, then fp32)
-    float bc2_sqrt;       // sqrt(1 - beta2^t)
+    AdamStatic st;
+    StepScalars sc;
 };
 
 template <int VEC>
@@ -187,14 +184,10 @@ __global__ __launch_bounds__(256) void train_step_kernel(
             float po[VEC], mo[VEC], vo[VEC];
 #pragma unroll
             for (int q = 0; q < VEC; ++q) {
-                const float p = pr[c][q];
-                const float g = gs[q] + ac.wd * p;                 // grad.add(param, alpha=wd)
-                const float m1 = mr[c][q] + ac.w1 * (g - mr[c][q]);  // exp_avg.lerp_(grad, 1-beta1)
-                const float v1 = vr[c][q] * ac.b2 + ac.w2 * g * g;   // mul_(beta2).addcmul_(g,g,1-beta2)
-                const float den = sqrtf(v1) / ac.bc2_sqrt + ac.eps;
-                po[q] = p + ac.neg_step_size * (m1 / den);          // addcdiv_(exp_avg, denom, -step_size)
-                mo[q] = m1;
-                vo[q] = v1;
+                po[q] = pr[c][q];
+                mo[q] = mr[c][q];
+                vo[q] = vr[c][q];
+                adam_update(po[q], mo[q], vo[q], gs[q], ac.st, ac.sc);
             }
             store_vec<VEC>(Pout + e, po);
             store_vec<VEC>(M1 + e, mo);
@@ -255,18 +248,32 @@ Plan make_plan(const void *const *ptrs, int nptrs, int n, int m, int d)
     return pl;
 }
 
-AdamConst adam_const(double lr, double beta1, double beta2, double eps, double wd, int64_t step)
+AdamStatic adam_static(double beta1, double beta2, double eps, double wd)
+{
+    AdamStatic a;
+    a.w1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    a.wd = (float)wd;
+    return a;
+}
+
+StepScalars step_scalars(double lr, double beta1, double beta2, int64_t step)
 {
     // bias corrections in f64 as Python does (adam.py: 1 - beta**step, lr / bc1, bc2 ** 0.5)
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    StepScalars s;
+    s.neg_step_size = (float)(-(lr / bc1));
+    s.bc2_sqrt = (float)sqrt(bc2);
+    return s;
+}
+
+AdamConst adam_const(double lr, double beta1, double beta2, double eps, double wd, int64_t step)
+{
     AdamConst ac;
-    ac.w1 = (float)(1.0 - beta1);
-    ac.b2 = (float)beta2;
-    ac.w2 = (float)(1.0 - beta2);
-    ac.eps = (float)eps;
-    ac.wd = (float)wd;
-    ac.neg_step_size = (float)(-(lr / bc1));
-    ac.bc2_sqrt = (float)sqrt(bc2);
+    ac.st = adam_static(beta1, beta2, eps, wd);
+    ac.sc = step_scalars(lr, beta1, beta2, step);
     return ac;
 }
 
@@ -304,12 +311,91 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
+namespace {
+
+constexpr size_t kStatusBytes = 256;  // workspace[0..3] = int32 status word of the last resident launch
+
+int g_train_path = 0;  // 0 auto, 1 streaming, 2 resident (mfcd_set_train_path)
+
+int device_cus()
+{
+    static int cached = 0;
+    if (!cached) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            cached = cus;
+        else
+            cached = 256;  // MI355X
+    }
+    return cached;
+}
+
+struct ResidentLayout {
+    size_t sc_off, terms_off, mailbox_off, mailbox_bytes, total;
+};
+
+ResidentLayout resident_layout(int64_t N, int B, int d)
+{
+    ResidentLayout L;
+    const int64_t K = (N + B - 1) / B;
+    size_t off = kStatusBytes;
+    L.sc_off = off;
+    off += align256(sizeof(StepScalars) * (size_t)(K > 0 ? K : 1));
+    L.terms_off = off;
+    off += align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    L.mailbox_off = off;
+    L.mailbox_bytes = sizeof(unsigned long long) * (size_t)N * 3 * (size_t)d;
+    off += align256(L.mailbox_bytes > 0 ? L.mailbox_bytes : 1);
+    L.total = off;
+    return L;
+}
+
+size_t streaming_bytes(int64_t N, int n, int m, int d)
+{
+    return kStatusBytes + align256(sizeof(float) * (size_t)n * d) + align256(sizeof(float) * (size_t)m * d) +
+           align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
+}
+
+constexpr size_t kMaxMailboxBytes = (size_t)24 << 30;  // beyond this the streaming form is used
+
+bool resident_applies(int64_t N, int B, int n, int m, int d, mfcd_detail::ResidentPlan *out)
+{
+    if (g_train_path == 1 || N <= 0) return false;
+    const mfcd_detail::ResidentPlan pl = mfcd_detail::plan_resident(n, m, d, device_cus());
+    if (!pl.ok) return false;
+    if (resident_layout(N, B, d).mailbox_bytes > kMaxMailboxBytes) return false;
+    if (out) *out = pl;
+    return true;
+}
+
+// pinned staging buffer for the per-step scalar table (grow-only, guarded by an event)
+struct Stage {
+    std::mutex mu;
+    StepScalars *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+};
+Stage g_stage;
+
+}  // namespace
+
+extern "C" int mfcd_set_train_path(int mode)
+{
+    if (mode < 0 || mode > 2) return MFCD_EINVAL;
+    g_train_path = mode;
+    return 0;
+}
+
 extern "C" size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d)
 {
-    (void)B;
-    if (N < 0 || n <= 0 || m <= 0 || d <= 0) return 0;
-    return align256(sizeof(float) * (size_t)n * d) + align256(sizeof(float) * (size_t)m * d) +
-           align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    if (N < 0 || B <= 0 || n <= 0 || m <= 0 || d <= 0) return 0;
+    size_t need = streaming_bytes(N, n, m, d);
+    if (g_train_path != 1 && mfcd_detail::plan_resident(n, m, d, 256).ok) {
+        const ResidentLayout L = resident_layout(N, B, d);
+        if (L.mailbox_bytes <= kMaxMailboxBytes && L.total > need) need = L.total;
+    }
+    return need;
 }
 
 namespace {
@@ -327,7 +413,65 @@ int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *
     if (!samples || !workspace) return MFCD_EINVAL;
     if (workspace_bytes < mfcd_train_workspace_bytes(N, B, n, m, d)) return MFCD_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    char *ws = (char *)workspace;
+    const int64_t nsteps = (N + B - 1) / B;
+    int *status = (int *)workspace;
+    MFCD_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
+
+    mfcd_detail::ResidentPlan rp;
+    const bool resident = resident_applies(N, B, n, m, d, &rp);
+    if (g_train_path == 2 && !resident) return MFCD_EINVAL;
+    if (resident) {
+        // ---- persistent register-resident form: ONE launch for all nsteps (resident.hip) ----
+        if (nsteps > 0x7fffffff) return MFCD_EINVAL;
+        const ResidentLayout L = resident_layout(N, B, d);
+        char *base = (char *)workspace;
+        StepScalars *sc_dev = (StepScalars *)(base + L.sc_off);
+        float *terms_r = (float *)(base + L.terms_off);
+        unsigned long long *mailbox = (unsigned long long *)(base + L.mailbox_off);
+        {
+            std::lock_guard<std::mutex> lock(g_stage.mu);
+            if (!g_stage.ev) MFCD_HIP_TRY(hipEventCreateWithFlags(&g_stage.ev, hipEventDisableTiming));
+            else MFCD_HIP_TRY(hipEventSynchronize(g_stage.ev));  // previous upload has left the buffer
+            if (g_stage.cap < (size_t)nsteps) {
+                if (g_stage.host) (void)hipHostFree(g_stage.host);
+                g_stage.cap = (size_t)nsteps * 2;
+                MFCD_HIP_TRY(hipHostMalloc((void **)&g_stage.host, sizeof(StepScalars) * g_stage.cap, 0));
+            }
+            for (int64_t k = 0; k < nsteps; ++k) g_stage.host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
+            MFCD_HIP_TRY(hipMemcpyAsync(sc_dev, g_stage.host, sizeof(StepScalars) * (size_t)nsteps,
+                                        hipMemcpyHostToDevice, st));
+            MFCD_HIP_TRY(hipEventRecord(g_stage.ev, st));
+        }
+        MFCD_HIP_TRY(hipMemsetAsync(mailbox, 0, L.mailbox_bytes, st));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timing_us) {
+            MFCD_HIP_TRY(hipEventCreate(&e0));
+            MFCD_HIP_TRY(hipEventCreate(&e1));
+            MFCD_HIP_TRY(hipEventRecord(e0, st));
+        }
+        if (int rc = mfcd_detail::launch_resident_steps(rp, U, V, mU, vU, mV, vV, samples, N, B, n, m, d, sc_dev,
+                                                       adam_static(beta1, beta2, eps, weight_decay), mailbox, terms_r,
+                                                       status, (int)nsteps, st))
+            return rc;
+        if (timing_us) MFCD_HIP_TRY(hipEventRecord(e1, st));
+        if (loss_per_step) {
+            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms_r, N, B,
+                               loss_per_step);
+            MFCD_HIP_TRY(hipGetLastError());
+        }
+        if (timing_us) {
+            MFCD_HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            MFCD_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            timing_us[0] = timing_us[1] = timing_us[2] = ms * 1e3f / (float)nsteps;  // whole launch / steps
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        return 0;
+    }
+
+    // ---- streaming form: one launch per optimiser step ----
+    char *ws = (char *)workspace + kStatusBytes;
     float *Ualt = (float *)ws;
     ws += align256(sizeof(float) * (size_t)n * d);
     float *Valt = (float *)ws;
@@ -336,7 +480,6 @@ int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *
 
     const void *ptrs[] = {U, V, mU, vU, mV, vV, Ualt, Valt};
     const Plan pl = make_plan(ptrs, 8, n, m, d);
-    const int64_t nsteps = (N + B - 1) / B;
     std::vector<hipEvent_t> ev;
     if (timing_us) {
         ev.resize(2 * (size_t)nsteps);
@@ -424,9 +567,9 @@ extern "C" int mfcd_apply_step(float *U, float *V, float *mU, float *vU, float *
     if (int rc = check_common(U, V, n, m, d)) return rc;
     if (!mU || !vU || !mV || !vV || B < 0 || step < 1 || !workspace) return MFCD_EINVAL;
     if (B > 0 && (!samples || !g)) return MFCD_EINVAL;
-    if (workspace_bytes < mfcd_train_workspace_bytes(B, B, n, m, d)) return MFCD_EWORKSPACE;
+    if (workspace_bytes < streaming_bytes(B, n, m, d)) return MFCD_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    char *ws = (char *)workspace;
+    char *ws = (char *)workspace + kStatusBytes;
     float *Ualt = (float *)ws;
     ws += align256(sizeof(float) * (size_t)n * d);
     float *Valt = (float *)ws;

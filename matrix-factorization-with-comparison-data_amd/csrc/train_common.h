@@ -1,0 +1,46 @@
+// Shared between the streaming (train.hip) and resident (resident.hip) forms of the optimiser step.
+#pragma once
+#include "common.h"
+
+struct AdamStatic {
+    float w1;   // 1 - beta1
+    float b2;   // beta2
+    float w2;   // 1 - beta2
+    float eps;
+    float wd;
+};
+
+// Per-step bias-correction scalars, computed on the host in f64 exactly as Python does in
+// torch/optim/adam.py (1 - beta**step, lr / bc1, bc2 ** 0.5) and rounded to fp32 where ATen would.
+struct StepScalars {
+    float neg_step_size;  // -(lr / (1 - beta1^t))
+    float bc2_sqrt;       // sqrt(1 - beta2^t)
+};
+
+// One element of torch.optim.Adam's single-tensor step (coupled L2), same op order:
+//   g += wd*p; m = m + (1-b1)(g-m); v = v*b2 + (1-b2)*g*g; p += -step_size * (m / (sqrt(v)/bc2s + eps))
+__device__ __forceinline__ void adam_update(float &p, float &m1, float &m2, float gsparse, const AdamStatic &ac,
+                                            const StepScalars &sc)
+{
+    const float g = gsparse + ac.wd * p;
+    m1 = m1 + ac.w1 * (g - m1);
+    m2 = m2 * ac.b2 + ac.w2 * g * g;
+    const float den = sqrtf(m2) / sc.bc2_sqrt + ac.eps;
+    p = p + sc.neg_step_size * (m1 / den);
+}
+
+namespace mfcd_detail {
+
+struct ResidentPlan {
+    bool ok;
+    int Q, NW, blocks;
+};
+
+ResidentPlan plan_resident(int n, int m, int d, int num_cus);
+
+int launch_resident_steps(const ResidentPlan &pl, float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                          const mfcd_sample *samples, int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev,
+                          const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status, int K,
+                          hipStream_t st);
+
+}  // namespace mfcd_detail

@@ -117,6 +117,22 @@ class Workspace:
 
 _ws = Workspace()
 
+TRAIN_PATHS = {"auto": 0, "streaming": 1, "resident": 2}
+
+
+def set_train_path(mode):
+    """Select the form of the fused step: "auto" (default), "streaming" or "resident" (include/mfcd.h)."""
+    _lib.check(_lib.load().mfcd_set_train_path(TRAIN_PATHS[mode]))
+
+
+def check_status():
+    """Raise if the last resident launch gave up on a bounded wait (workspace status word). Synchronises."""
+    if _ws.buf is not None:
+        code = int(_ws.buf[:4].view(torch.int32).item())
+        if code != 0:
+            raise _lib.MfcdError(f"resident training kernel aborted (status {code}): a bounded in-kernel wait expired; "
+                                 "parameters are undefined")
+
 
 def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None):
     """Run ceil(N/B) optimiser steps over `samples_dev` (int32 [N,4] device records, in order).
@@ -188,6 +204,7 @@ def fit(model, train_loader, val_loader, optimizer, num_epochs, progress=None):
         vl, _, _ = eval_batches(U, V, val.ordered(vorder), vbs)
         per_epoch_val.append(vl)
     # one device->host transfer for the whole run (the reference syncs every step at 852)
+    check_status()
     tl = [python_float_sum(t.cpu().numpy()) / max(len(t), 1) for t in per_epoch_train]
     vl = [python_float_sum(t.cpu().numpy()) / max(len(t), 1) for t in per_epoch_val]
     return tl, vl

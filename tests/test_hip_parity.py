@@ -27,6 +27,20 @@ def dev():
     return torch.device("cuda:0")
 
 
+def resident_applies(n, m, d):
+    """Mirror of plan_resident (csrc/resident.hip): d a power of two <= 256 and the state fits the register files."""
+    return d <= 256 and (d & (d - 1)) == 0 and (n + m) * d <= 256 * 8 * 64 * 16
+
+
+@pytest.fixture(params=["streaming", "resident"])
+def path(request, dev):
+    """Run a training test once per form of the fused step (include/mfcd.h, mfcd_set_train_path)."""
+    from mfcd import engine
+    engine.set_train_path(request.param)
+    yield request.param
+    engine.set_train_path("auto")
+
+
 def _model_from(U0, V0, dev, lr, wd):
     import structure as S
     n, d = U0.shape
@@ -61,9 +75,11 @@ class ListDataset(torch.utils.data.Dataset):
 # (a) golden vectors
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", KATS)
-def test_kat_steps_match_reference(dev, name):
+def test_kat_steps_match_reference(dev, path, name):
     from mfcd import engine
     g = load_golden(name)
+    if path == "resident" and not resident_applies(g["U0"].shape[0], g["V0"].shape[0], g["U0"].shape[1]):
+        pytest.skip("resident form needs d to be a power of two")
     lr, wd = float(g["lr"]), float(g["wd"])
     model, opt = _model_from(g["U0"], g["V0"], dev, lr, wd)
     bind = engine.AdamBinding(model, opt)
@@ -100,7 +116,7 @@ def test_saturated_terms_and_zero_gradient(dev):
 
 
 @pytest.mark.parametrize("name", E2ES)
-def test_e2e_train_eval_metrics_match_reference(dev, name):
+def test_e2e_train_eval_metrics_match_reference(dev, path, name):
     """train_model / evaluate_model / metric functions of the drop-in module on the reference's own data."""
     import structure as S
     g = load_golden(name)
@@ -178,9 +194,11 @@ def _synthetic(n, m, d, N, seed, soft=False):
     (128, 96, 256, 130, 1, False),        # B = 1
     (2048, 1024, 32, 4096, 4096, False),  # one huge batch
 ])
-def test_train_epoch_matches_oracle(dev, orc, n, m, d, N, B, soft):
+def test_train_epoch_matches_oracle(dev, orc, path, n, m, d, N, B, soft):
     from mfcd import engine
     from oracle import oracle as O
+    if path == "resident" and not resident_applies(n, m, d):
+        pytest.skip("resident form does not apply to this shape")
     U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=n + d + N, soft=soft)
     lr, wd = 1e-3, 1e-5
     model, opt = _model_from(U0, V0, dev, lr, wd)
@@ -206,7 +224,7 @@ def test_train_epoch_matches_oracle(dev, orc, n, m, d, N, B, soft):
     assert abs(int(vc.sum()) - int(rc.sum())) <= int(near.sum())
 
 
-def test_properties_at_c2_size(dev):
+def test_properties_at_c2_size(dev, path):
     """Size-independent properties at BASELINE C2: run-to-run bit reproducibility, call-splitting
     invariance (k steps in one call == the same steps over two calls), lr=0 & wd=0 leaves U,V untouched."""
     from mfcd import engine
@@ -235,7 +253,7 @@ def test_properties_at_c2_size(dev):
     assert bind.step == 100
 
 
-def test_untouched_rows_move_by_weight_decay_only(dev, orc):
+def test_untouched_rows_move_by_weight_decay_only(dev, orc, path):
     """Dense Adam is not optional (SURVEY §7): rows outside the batch still move through wd*p."""
     from mfcd import engine
     n = m = 512
@@ -305,3 +323,27 @@ def test_uvt_stats_match_oracle(dev, orc, n, m, d):
         np.testing.assert_allclose(rs[:, col], ref_rs[:, col], rtol=0, atol=2e-5 * scale)
     assert scal[0] == pytest.approx(err2, rel=2e-5)
     assert scal[1] == pytest.approx(ref2, rel=2e-5)
+
+
+def test_forms_agree_and_resident_rejects_unsupported_shapes(dev):
+    from mfcd import _lib, engine
+    n, m, d, N, B = 512, 384, 32, 64 * 40 + 5, 64
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=11, soft=True)
+    st = _records(u, i, j, z, n, m, dev)
+    outs = {}
+    try:
+        for mode in ("streaming", "resident"):
+            engine.set_train_path(mode)
+            model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+            loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B)
+            engine.check_status()
+            outs[mode] = (model.U.data.cpu().numpy(), model.V.data.cpu().numpy(), loss.cpu().numpy())
+        for a, b in zip(outs["streaming"], outs["resident"]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)
+        engine.set_train_path("resident")
+        U0, V0, u, i, j, z = _synthetic(40, 40, 5, 64, seed=2)
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        with pytest.raises(_lib.MfcdError):
+            engine.train_steps(engine.AdamBinding(model, opt), _records(u, i, j, z, 40, 40, dev).dev, 64)
+    finally:
+        engine.set_train_path("auto")

@@ -1,0 +1,29 @@
+"""Diagnostic: fused-step kernel period across problem sizes (streaming regime check; not the product)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "matrix-factorization-with-comparison-data_amd")]
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+import numpy as np, torch
+import structure as S
+from mfcd import engine
+
+dev = torch.device("cuda:0")
+cases = [("C1", 256, 256, 8), ("nb", 1000, 1000, 2), ("C2", 4096, 4096, 64), ("C3f32", 16384, 16384, 128),
+         ("C4", 65536, 65536, 64), ("C5", 100000, 20000, 256)]
+for name, n, m, d in cases:
+    model = S.MatrixFactorization(n, m, d).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    bind = engine.AdamBinding(model, opt)
+    B, steps = 64, 300
+    rng = np.random.default_rng(0)
+    N = B * steps
+    rows = np.stack([rng.integers(0, n, N), rng.integers(0, m, N), rng.integers(0, m, N), rng.integers(0, 2, N)], 1).astype(np.float64)
+    st = engine.SampleStore(rows, n, m, dev)
+    engine.train_steps(bind, st.dev, B); torch.cuda.synchronize()
+    t0 = time.perf_counter(); engine.train_steps(bind, st.dev, B); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    k = [0, 0, 0]; engine.train_steps(bind, st.dev, B, kernel_us=k)
+    ab = 24 * (n + m) * d + 12 * B * d + 16 * B
+    print(f"{name:6s} n={n:6d} m={m:6d} d={d:3d} elems={(n+m)*d/1e6:7.2f}M  period={dt/steps*1e6:8.2f} us  "
+          f"algGB/s={ab/(dt/steps)/1e9:8.1f}  ({ab/(dt/steps)/8e12*100:5.1f}% of 8TB/s)  evpair avg/min={k[0]:.2f}/{k[1]:.2f} us", flush=True)
+    del model, opt, bind, st
+    torch.cuda.empty_cache()
