@@ -13,12 +13,29 @@
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
-// Sum over the 64 lanes; every lane gets the same value (butterfly, fixed order).
+// DPP lane move inside a row of 16 (no LDS round trip, unlike __shfl / ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 64 lanes; every lane gets the same value, fixed order:
+// quad (xor 1, xor 2) -> 8 (row_half_mirror) -> 16 (row_mirror) with DPP, then the four row sums through
+// v_readlane as (r0 + r1) + (r2 + r3).  After each stage the partner lanes hold identical partial sums,
+// so the mirrored reads are equivalent to xor 4 / xor 8 butterflies.
 __device__ __forceinline__ float wave_sum64(float x)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, MFCD_WAVE);
-    return x;
+    x += dpp_move<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x);  // row_half_mirror
+    x += dpp_move<0x140>(x);  // row_mirror
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ int wave_sum64_i(int x)

@@ -1,0 +1,43 @@
+// resident_inst.hip — instantiations of the resident kernel for ONE factor width (-DMFCD_RES_D=<d>), so the
+// widths build in parallel.  Slice sizes: Q in {1, 4, 16} registers per array (64..1024 elements per wave).
+#include "resident_kernel.h"
+
+#ifndef MFCD_RES_D
+#error "compile with -DMFCD_RES_D=<factor width>"
+#endif
+#define MFCD_CAT2(a, b) a##b
+#define MFCD_CAT(a, b) MFCD_CAT2(a, b)
+
+namespace {
+
+template <int D, int Q>
+bool launch_q(const mfcd_detail::ResidentArgs &a, int blocks, hipStream_t st)
+{
+    if constexpr ((64 * Q) % D == 0) {
+        if (a.B <= 64)
+            hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, true>), dim3(blocks), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, false>), dim3(blocks), dim3(256), 0, st, a);
+        return true;
+    } else {
+        return false;
+    }
+}
+
+}  // namespace
+
+extern "C" int MFCD_CAT(mfcd_resident_launch_d, MFCD_RES_D)(const mfcd_detail::ResidentArgs *a, int Q, int blocks,
+                                                           void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+    switch (Q) {
+        case 1: ok = launch_q<MFCD_RES_D, 1>(*a, blocks, st); break;
+        case 4: ok = launch_q<MFCD_RES_D, 4>(*a, blocks, st); break;
+        case 16: ok = launch_q<MFCD_RES_D, 16>(*a, blocks, st); break;
+        default: break;
+    }
+    if (!ok) return MFCD_EINVAL;
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}

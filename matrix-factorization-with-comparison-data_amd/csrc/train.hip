@@ -215,14 +215,18 @@ __global__ __launch_bounds__(256) void coeff_kernel(const float *__restrict__ U,
 }
 
 // out[k] = mean(terms[k*B .. min((k+1)*B,N))) — one wave per batch, fixed summation order.
-__global__ __launch_bounds__(64) void batch_mean_kernel(const float *__restrict__ terms, int64_t N, int B,
+// With `samples` set, terms[] holds sigmoid outputs p and the BCE term is formed here from p and the label
+// (the resident kernel keeps the logs off its critical path); otherwise terms[] holds ready BCE terms.
+__global__ __launch_bounds__(64) void batch_mean_kernel(const float *__restrict__ terms,
+                                                        const mfcd_sample *__restrict__ samples, int64_t N, int B,
                                                         float *__restrict__ out)
 {
     const int lane = threadIdx.x;
     const int64_t off = (int64_t)blockIdx.x * B;
     const int b = (int)((N - off) < B ? (N - off) : B);
     float acc = 0.0f;
-    for (int t = lane; t < b; t += MFCD_WAVE) acc += terms[off + t];
+    for (int t = lane; t < b; t += MFCD_WAVE)
+        acc += samples ? bce_term_f32(terms[off + t], samples[off + t].z) : terms[off + t];
     acc = wave_sum64(acc);
     if (lane == 0) out[blockIdx.x] = acc / (float)b;
 }
@@ -332,14 +336,18 @@ int device_cus()
 }
 
 struct ResidentLayout {
-    size_t sc_off, terms_off, mailbox_off, mailbox_bytes, total;
+    size_t dbg_off, sc_off, terms_off, mailbox_off, mailbox_bytes, total;
 };
+
+constexpr size_t kDbgBytes = 16 * 256 * 8 * 8;  // [<=4096 waves][8] u64 of the diagnostic build (tools/)
 
 ResidentLayout resident_layout(int64_t N, int B, int d)
 {
     ResidentLayout L;
     const int64_t K = (N + B - 1) / B;
     size_t off = kStatusBytes;
+    L.dbg_off = off;
+    off += kDbgBytes;
     L.sc_off = off;
     off += align256(sizeof(StepScalars) * (size_t)(K > 0 ? K : 1));
     L.terms_off = off;
@@ -451,11 +459,12 @@ int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *
         }
         if (int rc = mfcd_detail::launch_resident_steps(rp, U, V, mU, vU, mV, vV, samples, N, B, n, m, d, sc_dev,
                                                        adam_static(beta1, beta2, eps, weight_decay), mailbox, terms_r,
-                                                       status, (int)nsteps, st))
+                                                       status, (unsigned long long *)(base + L.dbg_off), (int)nsteps,
+                                                       st))
             return rc;
         if (timing_us) MFCD_HIP_TRY(hipEventRecord(e1, st));
         if (loss_per_step) {
-            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms_r, N, B,
+            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms_r, samples, N, B,
                                loss_per_step);
             MFCD_HIP_TRY(hipGetLastError());
         }
@@ -501,7 +510,8 @@ int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *
         MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(float) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
     }
     if (loss_per_step) {
-        hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms, N, B, loss_per_step);
+        hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms,
+                           (const mfcd_sample *)nullptr, N, B, loss_per_step);
         MFCD_HIP_TRY(hipGetLastError());
     }
     if (timing_us) {

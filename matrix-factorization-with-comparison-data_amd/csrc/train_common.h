@@ -40,7 +40,7 @@ ResidentPlan plan_resident(int n, int m, int d, int num_cus);
 
 int launch_resident_steps(const ResidentPlan &pl, float *U, float *V, float *mU, float *vU, float *mV, float *vV,
                           const mfcd_sample *samples, int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev,
-                          const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status, int K,
-                          hipStream_t st);
+                          const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status,
+                          unsigned long long *dbg, int K, hipStream_t st);
 
 }  // namespace mfcd_detail

@@ -9,7 +9,7 @@ import os
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libmfcd_hip.so")
+LIB_PATH = os.environ.get("MFCD_LIB") or os.path.join(_PKG_DIR, "libmfcd_hip.so")  # MFCD_LIB: diagnostic builds (tools/)
 
 _vp, _i32, _i64, _dbl, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
 

@@ -4,7 +4,7 @@
 Stated fp32 tolerances (the GPU sums a d-term dot product in wave-shuffle order, ATen in SIMD order,
 and hipcc contracts a*b+c into FMA; everything else is the same arithmetic):
   sigmoid outputs / losses      rtol 2e-5, atol 2e-7
-  parameters after k steps      atol 2e-6 (k <= 5 epochs of C1), moments rtol 1e-3
+  parameters after k steps      atol 2e-3*lr (= 2e-6 at lr 1e-3; k <= 5 epochs of C1), moments rtol 1e-3
   epoch losses                  atol 2e-6
   dense metrics                 atol 1e-4 (the north-star bound), typically < 1e-6
 """
@@ -29,7 +29,7 @@ def dev():
 
 def resident_applies(n, m, d):
     """Mirror of plan_resident (csrc/resident.hip): d a power of two <= 256 and the state fits the register files."""
-    return d <= 256 and (d & (d - 1)) == 0 and (n + m) * d <= 256 * 8 * 64 * 16
+    return 2 <= d <= 256 and (d & (d - 1)) == 0 and (n + m) * d <= 256 * 8 * 64 * 16
 
 
 @pytest.fixture(params=["streaming", "resident"])
@@ -131,8 +131,9 @@ def test_e2e_train_eval_metrics_match_reference(dev, path, name):
     np.testing.assert_allclose(vl, g["val_losses"], rtol=0, atol=2e-6)
     assert isinstance(tl, list) and isinstance(tl[0], float) and len(tl) == E
     U, V = model.U.data.cpu().numpy(), model.V.data.cpu().numpy()
-    np.testing.assert_allclose(U, g["U_final"], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(V, g["V_final"], rtol=0, atol=2e-6)
+    ptol = 2e-3 * lr  # parameter differences scale with the step size: 2e-6 at the default lr = 1e-3
+    np.testing.assert_allclose(U, g["U_final"], rtol=0, atol=ptol)
+    np.testing.assert_allclose(V, g["V_final"], rtol=0, atol=ptol)
     # north-star: UV^T reconstruction MSE vs the reference's factors
     mse = float(np.mean((U @ V.T - g["U_final"] @ g["V_final"].T) ** 2))
     assert mse < 1e-10
