@@ -137,6 +137,21 @@ int mfcd_apply_step(float *U, float *V, float *mU, float *vU, float *mV, float *
                     void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Data-parallel form with the dense exchange the north star names (RCCL all-reduce of the factor
+ * gradients): mfcd_dense_grad overwrites gradU [n][d], gradV [m][d] with THIS rank's share of the batch
+ * gradient (structure.py:848-850; divisor = the GLOBAL batch size; rows no local sample touches are 0);
+ * term_out[t] (nullable) receives the BCE term of local sample t.  After the caller has summed the
+ * buffers over ranks, mfcd_adam_dense applies torch.optim.Adam's step (structure.py:851) from them.
+ */
+int mfcd_dense_grad(const float *U, const float *V, const mfcd_sample *samples, int B, int n, int m,
+                    int d, int batch_divisor, float *gradU, float *gradV, float *term_out,
+                    void *stream);
+int mfcd_adam_dense(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                    const float *gradU, const float *gradV, int64_t step, int n, int m, int d,
+                    double lr, double beta1, double beta2, double eps, double weight_decay,
+                    void *stream);
+
+/*
  * Dense UV^T pass against X [n][m] fp32 without materialising UV^T (MFMA fp32 tiles, fused
  * epilogue).  Replaces the GEMM + reductions of compute_reconstruction_error
  * (structure.py:940-952) and of compute_alpha_and_norm_ratios (structure.py:982-996, 1003-1009,

@@ -61,13 +61,16 @@ __device__ __forceinline__ void store_vec(float *p, const float (&r)[VEC])
 }
 
 // E = 256 * VEC * CHUNKS elements per workgroup.
-template <int VEC, int CHUNKS>
+// MODE 0: the fused step.  MODE 1 (data-parallel, before the all-reduce): only this rank's dense gradient,
+// Gu/Gv[e] = sum of the local samples' row gradients (no Adam, parameters untouched).  MODE 2 (after the
+// all-reduce): Adam from the dense gradient Gu/Gv, no batch scan.
+template <int VEC, int CHUNKS, int MODE = 0>
 __global__ __launch_bounds__(256) void train_step_kernel(
     const float *__restrict__ Uin, const float *__restrict__ Vin, float *__restrict__ Uout,
     float *__restrict__ Vout, float *__restrict__ mU, float *__restrict__ vU, float *__restrict__ mV,
     float *__restrict__ vV, const mfcd_sample *__restrict__ batch, const float *__restrict__ g_in,
     int Bk, float inv_batch, int n, int m, int d, int blocksU, AdamConst ac,
-    float *__restrict__ loss_terms)
+    float *__restrict__ loss_terms, float *__restrict__ Gu, float *__restrict__ Gv)
 {
     constexpr int E = 256 * VEC * CHUNKS;
     extern __shared__ __attribute__((aligned(16))) float sg[];  // [(row_hi-row_lo)*d] sparse row gradients
@@ -86,22 +89,25 @@ __global__ __launch_bounds__(256) void train_step_kernel(
     float *__restrict__ Pout = isV ? Vout : Uout;
     float *__restrict__ M1 = isV ? mV : mU;
     float *__restrict__ M2 = isV ? vV : vU;
+    float *__restrict__ G = isV ? Gv : Gu;
 
     // ---- phase 0: put this workgroup's p, m, v loads in flight before touching the batch ----
     float pr[CHUNKS][VEC], mr[CHUNKS][VEC], vr[CHUNKS][VEC];
+    if constexpr (MODE != 1) {
 #pragma unroll
-    for (int c = 0; c < CHUNKS; ++c) {
-        const int64_t e = e0 + (int64_t)(c * 256 + tid) * VEC;
-        if (e < e1) {
-            load_vec<VEC>(Pin + e, pr[c]);
-            load_vec<VEC>(M1 + e, mr[c]);
-            load_vec<VEC>(M2 + e, vr[c]);
+        for (int c = 0; c < CHUNKS; ++c) {
+            const int64_t e = e0 + (int64_t)(c * 256 + tid) * VEC;
+            if (e < e1) {
+                load_vec<VEC>(Pin + e, pr[c]);
+                load_vec<VEC>(M1 + e, mr[c]);
+                load_vec<VEC>(M2 + e, vr[c]);
+            }
         }
     }
 
     // ---- phase 1: which samples of the batch touch my rows? ----
     int any = 0;
-    for (int base = 0; base < Bk; base += MFCD_WAVE) {
+    for (int base = 0; MODE != 2 && base < Bk; base += MFCD_WAVE) {
         const int t = base + lane;
         if (t < Bk) {
             const mfcd_sample s = batch[t];
@@ -111,9 +117,9 @@ __global__ __launch_bounds__(256) void train_step_kernel(
                 any |= (s.u >= row_lo && s.u < row_hi);
         }
     }
-    any = __syncthreads_or(any);
+    if constexpr (MODE != 2) any = __syncthreads_or(any);
 
-    if (any) {
+    if (MODE != 2 && any) {
         const int nsg = (row_hi - row_lo) * d;
         for (int k = tid; k < nsg; k += 256) sg[k] = 0.0f;
         __syncthreads();
@@ -168,30 +174,36 @@ __global__ __launch_bounds__(256) void train_step_kernel(
         __syncthreads();
     }
 
-    // ---- phase 2: dense Adam over my range ----
+    // ---- phase 2: dense Adam over my range (MODE 1: write the dense gradient instead) ----
 #pragma unroll
     for (int c = 0; c < CHUNKS; ++c) {
         const int loc = (c * 256 + tid) * VEC;
         const int64_t e = e0 + loc;
         if (e < e1) {
             float gs[VEC];
-            if (any) {
+            if constexpr (MODE == 2) {
+                load_vec<VEC>(G + e, gs);
+            } else if (any) {
                 load_vec<VEC>(sg + sg_off + loc, gs);
             } else {
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) gs[q] = 0.0f;
             }
-            float po[VEC], mo[VEC], vo[VEC];
+            if constexpr (MODE == 1) {
+                store_vec<VEC>(G + e, gs);
+            } else {
+                float po[VEC], mo[VEC], vo[VEC];
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                po[q] = pr[c][q];
-                mo[q] = mr[c][q];
-                vo[q] = vr[c][q];
-                adam_update(po[q], mo[q], vo[q], gs[q], ac.st, ac.sc);
+                for (int q = 0; q < VEC; ++q) {
+                    po[q] = pr[c][q];
+                    mo[q] = mr[c][q];
+                    vo[q] = vr[c][q];
+                    adam_update(po[q], mo[q], vo[q], gs[q], ac.st, ac.sc);
+                }
+                store_vec<VEC>(Pout + e, po);
+                store_vec<VEC>(M1 + e, mo);
+                store_vec<VEC>(M2 + e, vo);
             }
-            store_vec<VEC>(Pout + e, po);
-            store_vec<VEC>(M1 + e, mo);
-            store_vec<VEC>(M2 + e, vo);
         }
     }
 }
@@ -281,24 +293,26 @@ AdamConst adam_const(double lr, double beta1, double beta2, double eps, double w
     return ac;
 }
 
-template <int VEC, int CHUNKS>
+template <int VEC, int CHUNKS, int MODE>
 void launch_step(const Plan &pl, hipStream_t st, const float *Uin, const float *Vin, float *Uout, float *Vout,
                  float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
-                 float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms)
+                 float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu, float *Gv)
 {
-    hipLaunchKernelGGL((train_step_kernel<VEC, CHUNKS>), dim3(pl.blocksU + pl.blocksV), dim3(256), pl.lds, st, Uin,
-                       Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, m, d, pl.blocksU, ac,
-                       loss_terms);
+    hipLaunchKernelGGL((train_step_kernel<VEC, CHUNKS, MODE>), dim3(pl.blocksU + pl.blocksV), dim3(256), pl.lds, st,
+                       Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, m, d, pl.blocksU, ac,
+                       loss_terms, Gu, Gv);
 }
 
+template <int MODE = 0>
 void dispatch_step(const Plan &pl, hipStream_t st, const float *Uin, const float *Vin, float *Uout, float *Vout,
                    float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
-                   float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms)
+                   float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu = nullptr,
+                   float *Gv = nullptr)
 {
-#define MFCD_CASE(V, C)                                                                                         \
-    if (pl.vec == V && pl.chunks == C)                                                                          \
-        return launch_step<V, C>(pl, st, Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, m, \
-                                 d, ac, loss_terms);
+#define MFCD_CASE(V, C)                                                                                              \
+    if (pl.vec == V && pl.chunks == C)                                                                               \
+        return launch_step<V, C, MODE>(pl, st, Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, \
+                                       m, d, ac, loss_terms, Gu, Gv);
     MFCD_CASE(4, 1) MFCD_CASE(4, 2) MFCD_CASE(4, 4) MFCD_CASE(4, 8)
     MFCD_CASE(1, 1) MFCD_CASE(1, 2) MFCD_CASE(1, 4) MFCD_CASE(1, 8)
 #undef MFCD_CASE
@@ -590,5 +604,36 @@ extern "C" int mfcd_apply_step(float *U, float *V, float *mU, float *vU, float *
     MFCD_HIP_TRY(hipGetLastError());
     MFCD_HIP_TRY(hipMemcpyAsync(U, Ualt, sizeof(float) * (size_t)n * d, hipMemcpyDeviceToDevice, st));
     MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(float) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int mfcd_dense_grad(const float *U, const float *V, const mfcd_sample *samples, int B, int n, int m, int d,
+                               int batch_divisor, float *gradU, float *gradV, float *term_out, void *stream)
+{
+    if (int rc = check_common(U, V, n, m, d)) return rc;
+    if (!gradU || !gradV || B < 0 || batch_divisor <= 0) return MFCD_EINVAL;
+    if (B > 0 && !samples) return MFCD_EINVAL;
+    const void *ptrs[] = {U, V, gradU, gradV};
+    const Plan pl = make_plan(ptrs, 4, n, m, d);
+    AdamConst ac{};
+    dispatch_step<1>(pl, (hipStream_t)stream, U, V, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, samples,
+                     nullptr, B, 1.0f / (float)batch_divisor, n, m, d, ac, term_out, gradU, gradV);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mfcd_adam_dense(float *U, float *V, float *mU, float *vU, float *mV, float *vV, const float *gradU,
+                               const float *gradV, int64_t step, int n, int m, int d, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, void *stream)
+{
+    if (int rc = check_common(U, V, n, m, d)) return rc;
+    if (!mU || !vU || !mV || !vV || !gradU || !gradV || step < 1) return MFCD_EINVAL;
+    const void *ptrs[] = {U, V, mU, vU, mV, vV, gradU, gradV};
+    const Plan pl = make_plan(ptrs, 8, n, m, d);
+    const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step);
+    // element-wise: reading and writing the same element in place is safe (no gather in this mode)
+    dispatch_step<2>(pl, (hipStream_t)stream, U, V, U, V, mU, vU, mV, vV, nullptr, nullptr, 0, 0.0f, n, m, d, ac,
+                     nullptr, const_cast<float *>(gradU), const_cast<float *>(gradV));
+    MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -26,6 +26,8 @@ SIGNATURES = {
                                [_vp, _vp, _sz, _vp, _vp]),
     "mfcd_batch_coefficients": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfcd_apply_step": (_i32, [_vp] * 8 + [_i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _sz, _vp]),
+    "mfcd_dense_grad": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mfcd_adam_dense": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp]),
     "mfcd_uvt_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mfcd_uvt_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_uvt_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

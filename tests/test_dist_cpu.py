@@ -1,0 +1,135 @@
+"""CPU / gloo, world_size 2: the data-parallel sharding + collective logic of mfcd.dist with the compute steps
+served by the oracle (tests may use it; the product backend is HipCompute).  Checks that both exchange forms give
+the single-process result for batch_size = B * world_size, and that the replicas stay bit-identical."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class OracleCompute:
+    """Oracle-backed stand-in for mfcd.dist.HipCompute (numpy state, CPU tensors on the wire)."""
+
+    def __init__(self, U0, V0, lr, wd):
+        from oracle import oracle as O
+        self.O, self.orc = O, O.COracle()
+        self.st = O.new_state(U0, V0)
+        self.lr, self.wd, self.step = lr, wd, 0
+
+    @staticmethod
+    def _split(rec):
+        r = rec.numpy()
+        return r[:, 0].astype(np.int64), r[:, 1].astype(np.int64), r[:, 2].astype(np.int64), r[:, 3].copy().view(np.float32)
+
+    def _g(self, rec, divisor):
+        u, i, j, z = self._split(rec)
+        p, term = self.orc.forward(self.st["U"], self.st["V"], u, i, j, z)
+        one = np.float32(1.0)
+        den = np.maximum((one - p) * p, np.float32(1e-12))
+        a = (np.float32(1.0 / divisor) * (p - z) / den).astype(np.float32)
+        return (a * (one - p) * p).astype(np.float32), term
+
+    def _scatter(self, rec, g):
+        u, i, j, _ = self._split(rec)
+        dU, dV = np.zeros_like(self.st["U"]), np.zeros_like(self.st["V"])
+        U, V = self.st["U"], self.st["V"]
+        for t in range(len(u)):
+            dU[u[t]] += g[t] * (V[i[t]] - V[j[t]])
+            dV[i[t]] += g[t] * U[u[t]]
+            dV[j[t]] += -(g[t] * U[u[t]])
+        return dU, dV
+
+    def _adam(self, dU, dV):
+        self.step += 1
+        for nm, gr in (("U", dU), ("V", dV)):
+            self.orc.adam(self.st[nm], self.st["m" + nm], self.st["v" + nm], gr, self.step, lr=self.lr, wd=self.wd)
+
+    def coefficients(self, rec_local, divisor):
+        g, term = self._g(rec_local, divisor)
+        return torch.from_numpy(np.stack([g, term]))
+
+    def apply(self, rec_global, g_global):
+        self._adam(*self._scatter(rec_global, g_global.numpy()))
+
+    def dense_grad(self, rec_local, divisor):
+        g, term = self._g(rec_local, divisor)
+        dU, dV = self._scatter(rec_local, g)
+        return torch.from_numpy(np.concatenate([dU.reshape(-1), dV.reshape(-1)])), torch.from_numpy(term)
+
+    def adam_dense(self, grad):
+        n, d = self.st["U"].shape
+        g = grad.numpy()
+        self._adam(g[: n * d].reshape(n, d), g[n * d:].reshape(-1, d))
+
+
+def _worker(rank, world, port, mode, out_dir):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mfcd import dist as mdist
+        from mfcd.batching import pack_records
+        rng = np.random.default_rng(5)
+        n, m, d, B, N = 40, 30, 8, 16, 16 * 2 * 6 + 11       # short last global batch: rank 0 gets 11, rank 1 none
+        U0 = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+        V0 = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+        u, i = rng.integers(0, n, N), rng.integers(0, m, N)
+        j = (i + 1 + rng.integers(0, m - 1, N)) % m
+        z = rng.integers(0, 2, N).astype(np.float64)
+        stream = torch.from_numpy(pack_records(np.stack([u, i, j, z], 1), n, m))
+        comp = OracleCompute(U0, V0, 1e-3, 1e-5)
+        losses = mdist.train_steps_dp(comp, stream, B, mode=mode)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), U=comp.st["U"], V=comp.st["V"], mU=comp.st["mU"],
+                 vV=comp.st["vV"], losses=losses.numpy(), step=comp.step)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["allgather", "allreduce"])
+def test_two_rank_data_parallel_equals_single_process_big_batch(tmp_path, mode, orc):
+    from oracle import oracle as O
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (dict(np.load(tmp_path / f"r{r}.npz")) for r in range(world))
+    for k in ("U", "V", "mU", "vV", "losses"):
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=f"replicas diverged in {k}")
+    # single process, batch_size = B * world, same stream
+    rng = np.random.default_rng(5)
+    n, m, d, B, N = 40, 30, 8, 16, 16 * 2 * 6 + 11
+    U0 = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    V0 = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+    u, i = rng.integers(0, n, N), rng.integers(0, m, N)
+    j = (i + 1 + rng.integers(0, m - 1, N)) % m
+    z = rng.integers(0, 2, N).astype(np.float64)
+    ref = O.new_state(U0, V0)
+    ref_loss = orc.train_steps(ref, u, i, j, z, B * world, 0, lr=1e-3, wd=1e-5)
+    assert int(r0["step"]) == len(ref_loss) == 7
+    np.testing.assert_allclose(r0["losses"], ref_loss, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(r0["U"], ref["U"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(r0["V"], ref["V"], rtol=0, atol=5e-7)
+
+
+def test_shard_bounds_cover_each_global_batch_once():
+    from mfcd.dist import shard_bounds
+    for lo, hi, B, world in ((0, 128, 64, 2), (128, 139, 64, 2), (0, 100, 16, 8), (50, 50, 16, 4)):
+        seen = []
+        for r in range(world):
+            a, b = shard_bounds(lo, hi, B, r)
+            assert lo <= a <= b <= hi and b - a <= B
+            seen += list(range(a, b))
+        assert seen == list(range(lo, min(hi, lo + B * world)))

@@ -348,3 +348,39 @@ def test_forms_agree_and_resident_rejects_unsupported_shapes(dev):
             engine.train_steps(engine.AdamBinding(model, opt), _records(u, i, j, z, 40, 40, dev).dev, 64)
     finally:
         engine.set_train_path("auto")
+
+
+@pytest.mark.parametrize("mode", ["allgather", "allreduce"])
+def test_data_parallel_hip_backend_single_rank(dev, mode):
+    """mfcd.dist with the product backend (HipCompute) on a one-rank RCCL group: both exchange forms must
+    reproduce the fused step (the multi-rank logic itself is covered on CPU/gloo in test_dist_cpu.py)."""
+    import os
+    import torch.distributed as dist
+    from mfcd import dist as mdist, engine
+    n, m, d, N, B = 700, 500, 64, 64 * 30 + 21, 64
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=21)
+    st = _records(u, i, j, z, n, m, dev)
+    engine.set_train_path("streaming")
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        ref_loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).cpu().numpy()
+        ref_U, ref_V = model.U.data.cpu().numpy(), model.V.data.cpu().numpy()
+    finally:
+        engine.set_train_path("auto")
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        bind = engine.AdamBinding(model, opt)
+        losses = mdist.train_steps_dp(mdist.HipCompute(bind), st.dev, B, mode=mode).cpu().numpy()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert bind.step == len(ref_loss) == 31
+    np.testing.assert_allclose(losses, ref_loss, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(model.U.data.cpu().numpy(), ref_U, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(model.V.data.cpu().numpy(), ref_V, rtol=0, atol=1e-6)
