@@ -93,7 +93,7 @@ def spearman_and_svd(U, V, X_centred_rows_mean, X, alpha, ok_rows, row_block=204
         rx = rx - rx.mean(1, keepdim=True)
         rho[r0:r1] = (ra * rx).sum(1) / torch.sqrt((ra * ra).sum(1) * (rx * rx).sum(1))
     rho = rho.cpu().numpy()
-    scores = [float(r) for r, o in zip(rho, ok_rows) if o and not np.isnan(r)]
+    scores = [np.float64(r) for r, o in zip(rho, ok_rows) if o and not np.isnan(r)]  # spearmanr yields np.float64
     # singular values: X centred (n x m); UV^T centred has rank <= d -> spectrum from a d x d problem
     try:
         Xc = X - X_centred_rows_mean[:, None]

@@ -384,3 +384,66 @@ def test_data_parallel_hip_backend_single_rank(dev, mode):
     np.testing.assert_allclose(losses, ref_loss, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(model.U.data.cpu().numpy(), ref_U, rtol=0, atol=1e-6)
     np.testing.assert_allclose(model.V.data.cpu().numpy(), ref_V, rtol=0, atol=1e-6)
+
+
+def _describe(o):
+    if isinstance(o, dict):
+        return {"type": "dict", "items": {k: _describe(v) for k, v in o.items()}}
+    if isinstance(o, (list, tuple)):
+        d = {"type": type(o).__name__, "len": len(o)}
+        if len(o):
+            d["elem0"] = _describe(o[0])
+        return d
+    if isinstance(o, np.ndarray):
+        return {"type": "ndarray", "dtype": str(o.dtype), "shape": list(o.shape)}
+    mod = type(o).__module__
+    return {"type": type(o).__name__ if mod == "builtins" else mod + "." + type(o).__name__}
+
+
+def test_run_experiment_and_parameter_scan_keep_the_pkl_layout(dev, tmp_path):
+    """The 23-key result dict (structure.py:420-444) and the pickled list of {'params','results'} (172-200) have the
+    same keys, nesting, lengths and leaf types as the reference produced (tests/golden/result_schema.json)."""
+    import json
+    import os
+    import pickle
+    import structure as S
+    from conftest import GOLDEN
+    schema = json.load(open(os.path.join(GOLDEN, "result_schema.json")))
+    torch.manual_seed(3)
+    np.random.seed(3)
+    res = S.run_experiment(40, 30, 4, 0.5, 1.0, "cuda", 1e-3, 1e-5, reps=2, num_epochs=2)
+    assert _describe(res) == schema["run_experiment"]
+    assert 0.0 <= res["accuracy"][0] <= 1.0 and 0.3 < res["train_losses"][0][0] < 1.5
+    path = str(tmp_path / "sub" / "scan.pkl")
+    ret = S.parameter_scan(n=40, m=30, d=[2, 4], p=0.5, device="cuda", num_epochs=1, reps=1, save_path=path, save_every=1)
+    assert ret == []                                   # the reference returns [] once it has saved (structure.py:200-202)
+    with open(path, "rb") as f:
+        saved = pickle.load(f)
+    assert _describe(saved) == schema["parameter_scan_saved"]
+    assert saved[0]["params"] == schema["parameter_scan_saved_params0"]
+    ret2 = S.parameter_scan(n=40, m=30, d=2, p=0.5, device="cuda", num_epochs=1, reps=1)
+    assert len(ret2) == 1 and set(ret2[0]) == {"params", "results"}
+    losses, accs = S.evaluate_ground_truth(40, 30, 0.5, 4, 1.0, "cuda", K=1, reps=2)
+    assert len(losses) == len(accs) == 2 and all(0.5 < a <= 1.0 for a in accs)
+    scan = S.parameter_scan_ground_truth(40, 30, 0.5, [2, 4], 1.0, "cuda", 1)
+    assert len(scan) == 2 and set(scan[0]["results"]) == {"gt_loss", "gt_accuracy"}
+
+
+def test_full_pipeline_reproduces_reference_run_from_seeds(dev):
+    """generate_X -> split -> model -> train_model -> metrics, from the same seeds the reference used for fixture
+    e2e_c1 (C1 of BASELINE.json): everything host-side is RNG-identical, so the trained factors must match too."""
+    import structure as S
+    g = load_golden("e2e_c1.npz")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    X = S.generate_X(256, 256, 8, "cuda")
+    train, val, test = S.split_dataset_from_triplets(X, int(256 * 256 * 0.05 / 2), scale=1.0, K=1)
+    model = S.MatrixFactorization(256, 256, 8).to("cuda")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    tl, vl = S.train_model(model, train, val, opt, "cuda", num_epochs=5)
+    np.testing.assert_allclose(tl, g["train_losses"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(vl, g["val_losses"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(model.U.data.cpu().numpy(), g["U_final"], rtol=0, atol=2e-6)
+    te_loss, te_acc = S.evaluate_model(model, test, "cuda")
+    assert te_loss == pytest.approx(float(g["test_loss"]), abs=2e-6) and te_acc == pytest.approx(float(g["test_acc"]), abs=1e-12)
+    assert S.compute_reconstruction_error(model, X, 1.0) == pytest.approx(float(g["rec_error"]), abs=1e-5)
