@@ -5,6 +5,11 @@
 
 #include "mfcd.h"
 
+// No implicit FMA contraction anywhere in the device code: the reference rounds every product before it is
+// summed (it materialises u*(vi-vj), g*(vi-vj), g*u as tensors), and contraction chosen per inlining context
+// would make two copies of the same source round differently.  fma is written explicitly where ATen uses it.
+#pragma clang fp contract(off)
+
 #define MFCD_WAVE 64
 
 #define MFCD_HIP_TRY(expr)                        \
@@ -51,6 +56,7 @@ __device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + ex
 // F.binary_cross_entropy element term with ATen's clamp of the logs at -100 (structure.py:849).
 __device__ __forceinline__ float bce_term_f32(float p, float z)
 {
+#pragma clang fp contract(off)
     const float l1 = fmaxf(log1pf(-p), -100.0f);
     const float l0 = fmaxf(logf(p), -100.0f);
     return (z - 1.0f) * l1 - z * l0;
@@ -60,6 +66,7 @@ __device__ __forceinline__ float bce_term_f32(float p, float z)
 // BCE backward (grad/B)*(p-z)/max((1-p)p,1e-12) followed by sigmoid backward *(1-p)*p.
 __device__ __forceinline__ float bce_sigmoid_backward_f32(float p, float z, float inv_batch)
 {
+#pragma clang fp contract(off)
     const float den = fmaxf((1.0f - p) * p, 1e-12f);
     const float a = inv_batch * (p - z) / den;
     return a * (1.0f - p) * p;
@@ -71,6 +78,6 @@ __device__ __forceinline__ float wave_score(const float *__restrict__ U, const f
 {
     const float *ur = U + (int64_t)u * d, *vi = V + (int64_t)i * d, *vj = V + (int64_t)j * d;
     float acc = 0.0f;
-    for (int k = lane; k < d; k += MFCD_WAVE) acc += ur[k] * (vi[k] - vj[k]);
+    for (int k = lane; k < d; k += MFCD_WAVE) acc += ur[k] * (vi[k] - vj[k]);  // product rounded, then summed (torch.sum(u*(vi-vj)))
     return wave_sum64(acc);
 }

@@ -93,6 +93,8 @@ int launch_resident_steps(const ResidentPlan &pl, float *U, float *V, float *mU,
     a.U = U; a.V = V; a.mU = mU; a.vU = vU; a.mV = mV; a.vV = vV;
     a.samples = samples; a.sc = sc_dev; a.mailbox = mailbox; a.loss_terms = loss_terms; a.status = status;
     a.N = N; a.B = B; a.n = n; a.m = m; a.K = K; a.NW = pl.NW; a.ac = ac;
+    const char *la = getenv("MFCD_RESIDENT_LOOKAHEAD");  // tuning/test override: 0 disables look-ahead publishing
+    a.lookahead = la ? atoi(la) : 4;
     ResidentLauncher fn = launcher_for(d);
     if (!fn) return MFCD_EINVAL;
     return fn(&a, pl.Q, pl.blocks, (void *)st);

@@ -14,10 +14,10 @@ template <int D, int Q>
 bool launch_q(const mfcd_detail::ResidentArgs &a, int blocks, hipStream_t st)
 {
     if constexpr ((64 * Q) % D == 0) {
-        if (a.B <= 64)
-            hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, true>), dim3(blocks), dim3(256), 0, st, a);
+        if (a.B <= 64 && a.lookahead > 0)
+            hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, 4>), dim3(blocks), dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, false>), dim3(blocks), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, 0>), dim3(blocks), dim3(256), 0, st, a);
         return true;
     } else {
         return false;

@@ -44,6 +44,7 @@ struct ResidentArgs {
     u64 *dbg;                // [NW][8] cycle accounting (diagnostic build only)
     int64_t N;
     int B, n, m, K, NW;
+    int lookahead;           // 0: publish right before use (any B); >0: look-ahead form (B <= 64)
     AdamStatic ac;
 };
 
@@ -63,10 +64,13 @@ struct Masks {
 };
 
 // D: factor width (power of two <= 256).  Q: registers per array per lane (slice = 64*Q elements).
-// SMALLB: every batch fits one 64-record chunk (B <= 64, the reference's fixed batch size): the masks of
-// the next batch are computed off the critical path and the rows the next batch needs are updated and
-// published before the rest of the slice.
-template <int D, int Q, bool SMALLB>
+// LOOK = 0: any batch size, chunked scan, rows published right after the step that precedes their use.
+// LOOK = W > 0 (B <= 64, the reference's fixed batch size): look-ahead publishing.  The value a consumer needs
+//   at step k is S_{k-1}(R); if batches j+1..k-1 do not touch R it is a pure function of the owner's state S_j
+//   (k-1-j dense-only Adam updates), so the owner publishes it at the end of step j = max(k-W, last touch of R
+//   before k) from a rolled-forward register copy.  The memory-side hand-off then overlaps W-1 steps of work
+//   instead of sitting on every step's critical chain.  Same arithmetic in the same order -> identical bits.
+template <int D, int Q, int LOOK>
 __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 {
     constexpr int S = D >= 64 ? D / 64 : 1;    // registers per row (gathered layout: lane <-> column lane + 64*s)
@@ -134,12 +138,12 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 
     // One sample (lane tl of chunk `base` of batch k) that touches my rows: fetch the other rows, form g,
     // accumulate the row gradients of my rows into gr[].  Returns false when a bounded wait expired.
-    auto process_hit = [&](const mfcd_sample &s, const Masks &M, int tl, int64_t pos, unsigned tag,
+    // `hs` is the sample itself (wave-uniform), `M`/`tl` say which of its rows are mine.
+    auto process_hit = [&](const mfcd_sample &hs, const Masks &M, int tl, int64_t pos, unsigned tag,
                            float inv_batch) -> bool {
-        const int rows[3] = {__shfl(s.u, tl, MFCD_WAVE), __shfl(s.i, tl, MFCD_WAVE) + a.n,
-                             __shfl(s.j, tl, MFCD_WAVE) + a.n};
+        const int rows[3] = {hs.u, hs.i + a.n, hs.j + a.n};
         const bool own[3] = {(bool)((M.mu >> tl) & 1ull), (bool)((M.mi >> tl) & 1ull), (bool)((M.mj >> tl) & 1ull)};
-        const float zz = __shfl(s.z, tl, MFCD_WAVE);
+        const float zz = hs.z;
         const u64 *slot = a.mailbox + pos * 3 * D;
 
         // the three rows in gathered layout (zero beyond column D)
@@ -224,92 +228,118 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         return true;
     };
 
-    if constexpr (SMALLB) {
-        // ================= B <= 64: software-pipelined masks, critical rows first =================
-        mfcd_sample rec_cur = load_record(a.samples, 0, batch_size(0), 0, lane);
-        mfcd_sample rec_next = rec_cur;
-        if (a.K > 1) rec_next = load_record(a.samples, (int64_t)a.B, batch_size(1), 0, lane);
-        StepScalars sc = a.sc[0];
-        Masks Mc = scan(rec_cur, batch_size(0), 0);
-        {   // initial values of the rows batch 0 needs, tag 1
-            u64 mask = Mc.mu | Mc.mi | Mc.mj;
-            while (mask) {
-                const int tl = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                if ((Mc.mu >> tl) & 1ull) store_row(__shfl(rec_cur.u, tl, MFCD_WAVE), (int64_t)tl * 3 + 0, 1u);
-                if ((Mc.mi >> tl) & 1ull) store_row(__shfl(rec_cur.i, tl, MFCD_WAVE) + a.n, (int64_t)tl * 3 + 1, 1u);
-                if ((Mc.mj >> tl) & 1ull) store_row(__shfl(rec_cur.j, tl, MFCD_WAVE) + a.n, (int64_t)tl * 3 + 2, 1u);
-            }
-        }
-        Masks Mn = Mc;
-        if (a.K > 1) Mn = scan(rec_next, batch_size(1), 0);
-
-        for (int k = 0; k < a.K; ++k) {
-            const int64_t pos0 = (int64_t)k * a.B;
-            const float inv_batch = 1.0f / (float)batch_size(k);
-            // prefetch two steps ahead: consumed (scanned) at the end of this step, off the critical path
-            mfcd_sample rec_nn = rec_next;
-            if (k + 2 < a.K) rec_nn = load_record(a.samples, (int64_t)(k + 2) * a.B, batch_size(k + 2), 0, lane);
-            const StepScalars sc_next = a.sc[k + 1 < a.K ? k + 1 : k];
+    if constexpr (LOOK > 0) {
+        // ================= B <= 64: look-ahead publishing over a window of LOOK batches =================
+        // Steady state per step and wave: one prefetched 16-byte record load, three ballots, Adam on the slice.
+        // Only the ballot masks of the window live in registers (SGPRs); the records of a batch are re-read
+        // (one scalar load per sample, one vector load per batch for the touch tests) only when a hit or a
+        // publish candidate actually occurs — about one wave-step in ten.
+        constexpr int W = LOOK;
+        const int last_B = (int)(a.N - (int64_t)(a.K - 1) * a.B);
+        auto bsize = [&](int step) { return step < a.K - 1 ? a.B : (step == a.K - 1 ? last_B : 0); };
+        auto sample_of = [&](int step, int tl) {   // wave-uniform address -> scalar load
+            return a.samples[(int64_t)step * a.B + __builtin_amdgcn_readfirstlane(tl)];
+        };
+        auto touches = [&](int step, int R) {      // does batch `step` touch global row R ?
+            const mfcd_sample s = load_record(a.samples, (int64_t)step * a.B, bsize(step), 0, lane);
+            return __ballot(s.u == R || s.i + a.n == R || s.j + a.n == R) != 0ull;
+        };
+        Masks Mw[W + 1];          // Mw[b] = my rows in batch j+b, j = the step just finished
+        Mw[0].mu = Mw[0].mi = Mw[0].mj = 0ull;  // before step 0: "batch -1" is empty
 #pragma unroll
-            for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
+        for (int b2 = 1; b2 <= W; ++b2)
+            Mw[b2] = scan(load_record(a.samples, (int64_t)(b2 - 1) * a.B, bsize(b2 - 1), 0, lane), bsize(b2 - 1), 0);
+        mfcd_sample rec_new = load_record(a.samples, (int64_t)W * a.B, bsize(W), 0, lane);  // batch W, used at k = 0
 
-            // ---- critical: this step's hits ----
-            u64 mask = Mc.mu | Mc.mi | Mc.mj;
-            while (mask) {
-                const int tl = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                if (!process_hit(rec_cur, Mc, tl, pos0 + tl, (unsigned)k + 1u, inv_batch)) return;
-            }
-            [[maybe_unused]] const u64 t_adam0 = STAMP();
-            // ---- critical: rows the next batch needs -> Adam on just those registers, then publish ----
-            bool done[Q];
+        // publish, from the state after step j, every (k, R) whose turn it is (see the template comment)
+        auto publish_phase = [&](int j, bool first) {
+            const bool touched_now = (Mw[0].mu | Mw[0].mi | Mw[0].mj) != 0ull;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) done[q] = false;
-            if (k + 1 < a.K) {
-                u64 pm = Mn.mu | Mn.mi | Mn.mj;
-                const int64_t npos0 = pos0 + a.B;
+            for (int kk = 1; kk <= W; ++kk) {
+                const int k = j + kk;
+                u64 pm = Mw[kk].mu | Mw[kk].mi | Mw[kk].mj;
+                if (pm == 0ull || k >= a.K) continue;
+                if (kk < W && !first && !touched_now) continue;   // none of my rows was touched by batch j
                 while (pm) {
                     const int tl = __ffsll((long long)pm) - 1;
                     pm &= pm - 1;
-                    const int rows[3] = {__shfl(rec_next.u, tl, MFCD_WAVE), __shfl(rec_next.i, tl, MFCD_WAVE) + a.n,
-                                         __shfl(rec_next.j, tl, MFCD_WAVE) + a.n};
-                    const bool fl[3] = {(bool)((Mn.mu >> tl) & 1ull), (bool)((Mn.mi >> tl) & 1ull),
-                                        (bool)((Mn.mj >> tl) & 1ull)};
+                    const mfcd_sample sk = sample_of(k, tl);
+                    const int rows[3] = {sk.u, sk.i + a.n, sk.j + a.n};
+                    const bool fl[3] = {(bool)((Mw[kk].mu >> tl) & 1ull), (bool)((Mw[kk].mi >> tl) & 1ull),
+                                        (bool)((Mw[kk].mj >> tl) & 1ull)};
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         if (!fl[r]) continue;
-                        const int q0 = reg_of(rows[r]);
+                        const int R = rows[r];
+                        bool later_touch = false;   // a batch in (j, k) touches R -> published after that step instead
+#pragma unroll
+                        for (int b2 = 1; b2 < kk; ++b2) later_touch = later_touch || touches(j + b2, R);
+                        if (later_touch) continue;
+                        if (kk < W && !first && !touches(j, R)) continue;  // already published when k entered the window
+                        // roll the registers of row R forward over steps j+1 .. k-1 (dense-only updates)
+                        const int q0 = reg_of(R);
+                        float pp[S], mm1[S], mm2[S];
+#pragma unroll
+                        for (int s2 = 0; s2 < S; ++s2) pp[s2] = mm1[s2] = mm2[s2] = 0.0f;
 #pragma unroll
                         for (int q = 0; q < Q; ++q) {
-                            if (q >= q0 && q < q0 + S && !done[q]) {
-                                adam_update(p[q], m1[q], m2[q], gr[q], a.ac, sc);
-                                done[q] = true;
+                            if (q >= q0 && q < q0 + S) {
+                                const int s2 = D >= 64 ? (q * 64 % D) / 64 : 0;
+                                pp[s2] = p[q];
+                                mm1[s2] = m1[q];
+                                mm2[s2] = m2[q];
                             }
                         }
-                        store_row(rows[r], (npos0 + tl) * 3 + r, (unsigned)k + 2u);
+#pragma unroll
+                        for (int b2 = 1; b2 < kk; ++b2) {
+                            const StepScalars scb = a.sc[j + b2];
+#pragma unroll
+                            for (int s2 = 0; s2 < S; ++s2) adam_update(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scb);
+                        }
+                        u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + r) * D;
+                        const unsigned tag = (unsigned)k + 1u;
+                        if constexpr (D >= 64) {
+#pragma unroll
+                            for (int s2 = 0; s2 < S; ++s2) store_granule(dst + s2 * 64 + lane, tag, pp[s2]);
+                        } else {
+                            if (lane / D == (R - Rlo) % RPR) store_granule(dst + lcol, tag, pp[0]);
+                        }
                     }
                 }
             }
-            [[maybe_unused]] const u64 t_adam1 = STAMP();
-            DBG_ADD(4, t_adam1 - t_adam0);
-            // ---- off the critical path: the rest of my slice, then the masks of batch k+2 ----
-            // branch-free so the Q independent update chains interleave (a branch per register serialises them);
-            // registers already updated above keep their values
+        };
+
+        publish_phase(-1, true);
+
+        StepScalars sc_cur = a.sc[0];
+        for (int k = 0; k < a.K; ++k) {
+            // slide the masks: Mw[0] becomes batch k; scan batch k+W (record prefetched during the last step)
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                float pn = p[q], m1n = m1[q], m2n = m2[q];
-                adam_update(pn, m1n, m2n, gr[q], a.ac, sc);
-                p[q] = done[q] ? p[q] : pn;
-                m1[q] = done[q] ? m1[q] : m1n;
-                m2[q] = done[q] ? m2[q] : m2n;
+            for (int b2 = 0; b2 < W; ++b2) Mw[b2] = Mw[b2 + 1];
+            Mw[W] = scan(rec_new, bsize(k + W), 0);
+            rec_new = load_record(a.samples, (int64_t)(k + W + 1) * a.B, bsize(k + W + 1), 0, lane);
+            const StepScalars sc_next = a.sc[k + 1 < a.K ? k + 1 : k];
+
+#pragma unroll
+            for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
+            u64 mask = Mw[0].mu | Mw[0].mi | Mw[0].mj;
+            if (mask) {
+                const int64_t pos0 = (int64_t)k * a.B;
+                const float inv_batch = 1.0f / (float)bsize(k);
+                while (mask) {
+                    const int tl = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    if (!process_hit(sample_of(k, tl), Mw[0], tl, pos0 + tl, (unsigned)k + 1u, inv_batch)) return;
+                }
             }
-            DBG_ADD(3, STAMP() - t_adam1);
-            rec_cur = rec_next;
-            rec_next = rec_nn;
-            Mc = Mn;
-            if (k + 2 < a.K) Mn = scan(rec_next, batch_size(k + 2), 0);
-            sc = sc_next;
+            [[maybe_unused]] const u64 t_adam0 = STAMP();
+#pragma unroll
+            for (int q = 0; q < Q; ++q) adam_update(p[q], m1[q], m2[q], gr[q], a.ac, sc_cur);
+            [[maybe_unused]] const u64 t_adam1 = STAMP();
+            DBG_ADD(3, t_adam1 - t_adam0);
+            publish_phase(k, false);
+            DBG_ADD(4, STAMP() - t_adam1);
+            sc_cur = sc_next;
         }
     } else {
         // ================= any B: chunked scan, publish after the whole slice is updated =================
@@ -345,7 +375,12 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                 while (mask) {
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    if (!process_hit(s, M, tl, pos0 + base + tl, (unsigned)k + 1u, inv_batch)) return;
+                    mfcd_sample hs;
+                    hs.u = __shfl(s.u, tl, MFCD_WAVE);
+                    hs.i = __shfl(s.i, tl, MFCD_WAVE);
+                    hs.j = __shfl(s.j, tl, MFCD_WAVE);
+                    hs.z = __shfl(s.z, tl, MFCD_WAVE);
+                    if (!process_hit(hs, M, tl, pos0 + base + tl, (unsigned)k + 1u, inv_batch)) return;
                 }
             }
 #pragma unroll

@@ -17,16 +17,25 @@ struct StepScalars {
     float bc2_sqrt;       // sqrt(1 - beta2^t)
 };
 
-// One element of torch.optim.Adam's single-tensor step (coupled L2), same op order:
-//   g += wd*p; m = m + (1-b1)(g-m); v = v*b2 + (1-b2)*g*g; p += -step_size * (m / (sqrt(v)/bc2s + eps))
+// One element of torch.optim.Adam's single-tensor step (coupled L2).  The operation sequence is pinned
+// (explicit fmaf, contraction off) so that every inlined copy rounds identically — the resident kernel relies on
+// a rolled-forward copy of a row matching the in-place update bit for bit — and it mirrors ATen's CPU kernels:
+//   grad.add(param, alpha=wd)            -> fma(wd, p, g)                    (vec::fmadd)
+//   exp_avg.lerp_(grad, 1-b1)            -> fma(1-b1, g - m, m)              (weight < 0.5 branch, vec::fmadd)
+//   exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2) -> (v*b2) + ((1-b2)*g)*g          (no fma)
+//   denom = sqrt(v)/bc2_sqrt + eps ;  param.addcdiv_(m, denom, -step_size)  -> p + ((-step_size)*m)/denom
 __device__ __forceinline__ void adam_update(float &p, float &m1, float &m2, float gsparse, const AdamStatic &ac,
                                             const StepScalars &sc)
 {
-    const float g = gsparse + ac.wd * p;
-    m1 = m1 + ac.w1 * (g - m1);
-    m2 = m2 * ac.b2 + ac.w2 * g * g;
+#pragma clang fp contract(off)
+    const float g = __builtin_fmaf(ac.wd, p, gsparse);
+    m1 = __builtin_fmaf(ac.w1, g - m1, m1);
+    const float v_scaled = m2 * ac.b2;
+    const float gg = (ac.w2 * g) * g;
+    m2 = v_scaled + gg;
     const float den = sqrtf(m2) / sc.bc2_sqrt + ac.eps;
-    p = p + sc.neg_step_size * (m1 / den);
+    const float num = sc.neg_step_size * m1;
+    p = p + num / den;
 }
 
 namespace mfcd_detail {

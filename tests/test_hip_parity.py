@@ -447,3 +447,29 @@ def test_full_pipeline_reproduces_reference_run_from_seeds(dev):
     te_loss, te_acc = S.evaluate_model(model, test, "cuda")
     assert te_loss == pytest.approx(float(g["test_loss"]), abs=2e-6) and te_acc == pytest.approx(float(g["test_acc"]), abs=1e-12)
     assert S.compute_reconstruction_error(model, X, 1.0) == pytest.approx(float(g["rec_error"]), abs=1e-5)
+
+
+@pytest.mark.parametrize("n,m,d,N", [(4096, 4096, 64, 64 * 200 + 9), (300, 200, 128, 64 * 50), (64, 48, 8, 64 * 60 + 1),
+                                      (1000, 1000, 2, 64 * 40), (6, 5, 16, 64 * 30)])
+def test_lookahead_publishing_is_bit_identical(dev, n, m, d, N):
+    """Look-ahead publishing only changes WHEN a row is handed over, never its value: the resident kernel with and
+    without it must agree bit for bit (small tables make rows recur inside the window, the deferred-publish case)."""
+    import os
+    from mfcd import engine
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=n + d)
+    st = _records(u, i, j, z, n, m, dev)
+    outs = []
+    engine.set_train_path("resident")
+    try:
+        for look in ("0", "4"):
+            os.environ["MFCD_RESIDENT_LOOKAHEAD"] = look
+            model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+            loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, 64)
+            engine.check_status()
+            outs.append((model.U.data.clone(), model.V.data.clone(), loss.clone(),
+                         opt.state[model.V]["exp_avg_sq"].clone()))
+    finally:
+        os.environ.pop("MFCD_RESIDENT_LOOKAHEAD", None)
+        engine.set_train_path("auto")
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
