@@ -258,6 +258,12 @@ def _run():
     kavg, kmin, kmax = runner.kernel_sample()
     abytes = algorithmic_bytes_per_step(cfg)
     achieved = abytes / (period_us * 1e-6) / 1e9
+    traffic = None   # HBM bytes per optimiser step from rocprofv3 --pmc passes of this same command (profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get("hbm_bytes_per_step")
+    except Exception:
+        pass
     out = {
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 6),
@@ -266,7 +272,7 @@ def _run():
                                "1049 steps/epoch + validation pass per epoch", "global_batch": cfg["B"],
                    "train_samples": runner.train.N, "parallelism": "single"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": abytes, "launch_period_us": round(period_us, 3),
                      "kernel_us_event_pairs": {"avg": round(kavg, 3), "min": round(kmin, 3), "max": round(kmax, 3)},
                      "kernel": kernel_name},

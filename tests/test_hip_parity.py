@@ -473,3 +473,34 @@ def test_lookahead_publishing_is_bit_identical(dev, n, m, d, N):
         engine.set_train_path("auto")
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,n,m,d,steps", [
+    ("C3-shape", 16384, 16384, 128, 24),      # BASELINE configs[2] shape (fp32 factors here)
+    ("C4-shape", 65536, 65536, 64, 16),       # BASELINE configs[3] shape
+    ("C5-shape", 100000, 20000, 256, 8),      # BASELINE configs[4] shape
+])
+def test_streaming_step_at_baseline_full_sizes(dev, orc, name, n, m, d, steps):
+    """BASELINE.json's larger shapes (fp32): a few optimiser steps of the streaming form against the oracle, plus
+    run-to-run bit reproducibility.  (bf16 factors of configs[2] are a later row)"""
+    from mfcd import engine
+    from oracle import oracle as O
+    B = 64
+    N = B * steps - 7
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=d + steps)
+    u[:40] = u[0]            # force duplicate users / items inside the first batch
+    i[:20] = i[0]
+    j[:20] = (i[0] + 1) % m
+    st = _records(u, i, j, z, n, m, dev)
+    outs = []
+    for _ in range(2):
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B)
+        outs.append((model.U.data.clone(), model.V.data.clone(), loss.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = O.new_state(U0, V0)
+    ref_loss = orc.train_steps(ref, u, i, j, z, B, 0, lr=1e-3, wd=1e-5, threads=8)
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), ref_loss, rtol=2e-5, atol=2e-6)
+    assert_close_with_rare_outliers(outs[0][0].cpu().numpy(), ref["U"], 2e-6, 1e-3, name + " U")
+    assert_close_with_rare_outliers(outs[0][1].cpu().numpy(), ref["V"], 2e-6, 1e-3, name + " V")
