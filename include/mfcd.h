@@ -88,6 +88,17 @@ size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d);
 int mfcd_set_train_path(int mode);
 
 /*
+ * Arithmetic flavour of Adam inside the RESIDENT form, where the step is bound by vector-ALU cycles
+ * (process-wide; the streaming form is HBM-bound and always uses the IEEE flavour):
+ *   1 fast (default)  same operation order, but sqrt is the hardware v_sqrt_f32 (<= 1 ulp) and the two
+ *                     divisions are reciprocal-multiply with one Newton correction (<= 1 ulp) instead of
+ *                     the IEEE-rounded expansions; the update differs by a few ulp (~1e-10 per step)
+ *   0 ieee            every operation IEEE-rounded, as ATen's CPU kernels
+ * Either flavour is deterministic and keeps every parity test within the stated tolerances.
+ */
+int mfcd_set_resident_math(int fast);
+
+/*
  * Runs ceil(N/B) sequential optimiser steps on the device, consuming `samples` in order in
  * batches of B (last one short, divisor = actual batch size).  One step replaces
  * structure.py:847-851: zero_grad, forward, BCE(mean), backward (gather + scatter-add of row

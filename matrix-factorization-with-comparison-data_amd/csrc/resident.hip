@@ -37,6 +37,8 @@ MFCD_DECL(2) MFCD_DECL(4) MFCD_DECL(8) MFCD_DECL(16) MFCD_DECL(32) MFCD_DECL(64)
 
 namespace mfcd_detail {
 
+int g_resident_math = 1;   // mfcd_set_resident_math: 1 = fast flavour (default), 0 = IEEE-rounded
+
 typedef int (*ResidentLauncher)(const ResidentArgs *, int, int, void *);
 
 static ResidentLauncher launcher_for(int d)
@@ -95,6 +97,8 @@ int launch_resident_steps(const ResidentPlan &pl, float *U, float *V, float *mU,
     a.N = N; a.B = B; a.n = n; a.m = m; a.K = K; a.NW = pl.NW; a.ac = ac;
     const char *la = getenv("MFCD_RESIDENT_LOOKAHEAD");  // tuning/test override: 0 disables look-ahead publishing
     a.lookahead = la ? atoi(la) : 4;
+    if (N + 64 * 8 >= ((int64_t)1 << 31)) a.lookahead = 0;   // the look-ahead form indexes samples with 32 bits
+    a.fast_math = g_resident_math;
     ResidentLauncher fn = launcher_for(d);
     if (!fn) return MFCD_EINVAL;
     return fn(&a, pl.Q, pl.blocks, (void *)st);

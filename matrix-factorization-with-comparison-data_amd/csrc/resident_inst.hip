@@ -14,10 +14,14 @@ template <int D, int Q>
 bool launch_q(const mfcd_detail::ResidentArgs &a, int blocks, hipStream_t st)
 {
     if constexpr ((64 * Q) % D == 0) {
-        if (a.B <= 64 && a.lookahead > 0)
-            hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, 4>), dim3(blocks), dim3(256), 0, st, a);
-        else
-            hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, 0>), dim3(blocks), dim3(256), 0, st, a);
+        const bool look = a.B <= 64 && a.lookahead > 0;
+#define MFCD_LAUNCH(L, F) \
+    hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, L, F>), dim3(blocks), dim3(256), 0, st, a)
+        if (look && a.fast_math) MFCD_LAUNCH(4, true);
+        else if (look) MFCD_LAUNCH(4, false);
+        else if (a.fast_math) MFCD_LAUNCH(0, true);
+        else MFCD_LAUNCH(0, false);
+#undef MFCD_LAUNCH
         return true;
     } else {
         return false;

@@ -45,6 +45,7 @@ struct ResidentArgs {
     int64_t N;
     int B, n, m, K, NW;
     int lookahead;           // 0: publish right before use (any B); >0: look-ahead form (B <= 64)
+    int fast_math;           // Adam arithmetic flavour: 0 IEEE-rounded, 1 v_sqrt / Newton-corrected rcp
     AdamStatic ac;
 };
 
@@ -70,7 +71,8 @@ struct Masks {
 //   (k-1-j dense-only Adam updates), so the owner publishes it at the end of step j = max(k-W, last touch of R
 //   before k) from a rolled-forward register copy.  The memory-side hand-off then overlaps W-1 steps of work
 //   instead of sitting on every step's critical chain.  Same arithmetic in the same order -> identical bits.
-template <int D, int Q, int LOOK>
+// FAST: Adam arithmetic flavour (train_common.h): false = IEEE-rounded div/sqrt, true = v_sqrt / Newton-corrected rcp.
+template <int D, int Q, int LOOK, bool FAST>
 __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 {
     constexpr int S = D >= 64 ? D / 64 : 1;    // registers per row (gathered layout: lane <-> column lane + 64*s)
@@ -230,43 +232,78 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 
     if constexpr (LOOK > 0) {
         // ================= B <= 64: look-ahead publishing over a window of LOOK batches =================
-        // Steady state per step and wave: one prefetched 16-byte record load, three ballots, Adam on the slice.
-        // Only the ballot masks of the window live in registers (SGPRs); the records of a batch are re-read
-        // (one scalar load per sample, one vector load per batch for the touch tests) only when a hit or a
-        // publish candidate actually occurs — about one wave-step in ten.
+        // Hot path per step and wave (no hit, no publish candidate — about nine wave-steps in ten): one prefetched
+        // 16-byte record load, one ballot, a handful of scalar moves, Adam on the slice.  Only ONE 64-bit mask per
+        // window batch lives in registers ("some sample of that batch touches a row of mine"); role masks and the
+        // records themselves are re-derived from a reload only when such a sample exists.
         constexpr int W = LOOK;
-        const int last_B = (int)(a.N - (int64_t)(a.K - 1) * a.B);
-        auto bsize = [&](int step) { return step < a.K - 1 ? a.B : (step == a.K - 1 ? last_B : 0); };
-        auto sample_of = [&](int step, int tl) {   // wave-uniform address -> scalar load
-            return a.samples[(int64_t)step * a.B + __builtin_amdgcn_readfirstlane(tl)];
+        const int N32 = (int)a.N;                                  // host guarantees N + 64*(W+2) < 2^31
+        const bool ownsU = Rlo < a.n, ownsV = Rhi > a.n;
+        const int ulo = Rlo, ucnt = (Rhi < a.n ? Rhi : a.n) - Rlo;                       // my user rows
+        const int vlo = (Rlo > a.n ? Rlo : a.n) - a.n, vcnt = Rhi - a.n - vlo;           // my item rows (item ids)
+        auto load_rec = [&](int step) {                            // this lane's record of batch `step`
+            mfcd_sample s;
+            s.u = s.i = s.j = -0x40000000;
+            s.z = 0.0f;
+            const int pos = step * a.B + lane;
+            if (lane < a.B && pos < N32) s = a.samples[pos];
+            return s;
         };
-        auto touches = [&](int step, int R) {      // does batch `step` touch global row R ?
-            const mfcd_sample s = load_record(a.samples, (int64_t)step * a.B, bsize(step), 0, lane);
+        auto any_mask = [&](const mfcd_sample &s) {                // inert lanes hold -2^30: never in range
+            bool h = false;
+            if (ownsU) h = (unsigned)(s.u - ulo) < (unsigned)ucnt;
+            if (ownsV) h = h || (unsigned)(s.i - vlo) < (unsigned)vcnt || (unsigned)(s.j - vlo) < (unsigned)vcnt;
+            return (u64)__ballot(h);
+        };
+        auto role_masks = [&](const mfcd_sample &s) {
+            Masks M;
+            M.mu = __ballot(ownsU && (unsigned)(s.u - ulo) < (unsigned)ucnt);
+            M.mi = __ballot(ownsV && (unsigned)(s.i - vlo) < (unsigned)vcnt);
+            M.mj = __ballot(ownsV && (unsigned)(s.j - vlo) < (unsigned)vcnt);
+            return M;
+        };
+        auto lane_sample = [&](const mfcd_sample &s, int tl) {     // record of lane tl as wave-uniform values
+            mfcd_sample r;
+            r.u = __builtin_amdgcn_readlane(s.u, tl);
+            r.i = __builtin_amdgcn_readlane(s.i, tl);
+            r.j = __builtin_amdgcn_readlane(s.j, tl);
+            r.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.z), tl));
+            return r;
+        };
+        auto touches = [&](int step, int R) {                      // does batch `step` touch global row R ?
+            const mfcd_sample s = load_rec(step);
             return __ballot(s.u == R || s.i + a.n == R || s.j + a.n == R) != 0ull;
         };
-        Masks Mw[W + 1];          // Mw[b] = my rows in batch j+b, j = the step just finished
-        Mw[0].mu = Mw[0].mi = Mw[0].mj = 0ull;  // before step 0: "batch -1" is empty
+
+        u64 anyw[W + 1];          // anyw[b] = any-mask of batch j+b, j = the step just finished
+        anyw[0] = 0ull;           // before step 0: "batch -1" is empty
 #pragma unroll
-        for (int b2 = 1; b2 <= W; ++b2)
-            Mw[b2] = scan(load_record(a.samples, (int64_t)(b2 - 1) * a.B, bsize(b2 - 1), 0, lane), bsize(b2 - 1), 0);
-        mfcd_sample rec_new = load_record(a.samples, (int64_t)W * a.B, bsize(W), 0, lane);  // batch W, used at k = 0
+        for (int b2 = 1; b2 <= W; ++b2) anyw[b2] = any_mask(load_rec(b2 - 1));
+        mfcd_sample rec_new = load_rec(W);                         // batch W, scanned at k = 0
 
         // publish, from the state after step j, every (k, R) whose turn it is (see the template comment)
         auto publish_phase = [&](int j, bool first) {
-            const bool touched_now = (Mw[0].mu | Mw[0].mi | Mw[0].mj) != 0ull;
+            u64 cand = anyw[W];
+            if (first || anyw[0] != 0ull) {
+#pragma unroll
+                for (int b2 = 1; b2 < W; ++b2) cand |= anyw[b2];
+            }
+            if (cand == 0ull) return;                              // the common case
 #pragma unroll
             for (int kk = 1; kk <= W; ++kk) {
                 const int k = j + kk;
-                u64 pm = Mw[kk].mu | Mw[kk].mi | Mw[kk].mj;
-                if (pm == 0ull || k >= a.K) continue;
-                if (kk < W && !first && !touched_now) continue;   // none of my rows was touched by batch j
+                if (anyw[kk] == 0ull || k >= a.K) continue;
+                if (kk < W && !first && anyw[0] == 0ull) continue; // none of my rows was touched by batch j
+                const mfcd_sample rk = load_rec(k);
+                const Masks Mk = role_masks(rk);
+                u64 pm = Mk.mu | Mk.mi | Mk.mj;
                 while (pm) {
                     const int tl = __ffsll((long long)pm) - 1;
                     pm &= pm - 1;
-                    const mfcd_sample sk = sample_of(k, tl);
+                    const mfcd_sample sk = lane_sample(rk, tl);
                     const int rows[3] = {sk.u, sk.i + a.n, sk.j + a.n};
-                    const bool fl[3] = {(bool)((Mw[kk].mu >> tl) & 1ull), (bool)((Mw[kk].mi >> tl) & 1ull),
-                                        (bool)((Mw[kk].mj >> tl) & 1ull)};
+                    const bool fl[3] = {(bool)((Mk.mu >> tl) & 1ull), (bool)((Mk.mi >> tl) & 1ull),
+                                        (bool)((Mk.mj >> tl) & 1ull)};
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         if (!fl[r]) continue;
@@ -294,7 +331,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                         for (int b2 = 1; b2 < kk; ++b2) {
                             const StepScalars scb = a.sc[j + b2];
 #pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) adam_update(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scb);
+                            for (int s2 = 0; s2 < S; ++s2) adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scb);
                         }
                         u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + r) * D;
                         const unsigned tag = (unsigned)k + 1u;
@@ -313,28 +350,31 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 
         StepScalars sc_cur = a.sc[0];
         for (int k = 0; k < a.K; ++k) {
-            // slide the masks: Mw[0] becomes batch k; scan batch k+W (record prefetched during the last step)
+            // slide the window: anyw[0] becomes batch k; scan batch k+W (record prefetched during the last step)
 #pragma unroll
-            for (int b2 = 0; b2 < W; ++b2) Mw[b2] = Mw[b2 + 1];
-            Mw[W] = scan(rec_new, bsize(k + W), 0);
-            rec_new = load_record(a.samples, (int64_t)(k + W + 1) * a.B, bsize(k + W + 1), 0, lane);
+            for (int b2 = 0; b2 < W; ++b2) anyw[b2] = anyw[b2 + 1];
+            anyw[W] = any_mask(rec_new);
+            rec_new = load_rec(k + W + 1);
             const StepScalars sc_next = a.sc[k + 1 < a.K ? k + 1 : k];
 
 #pragma unroll
             for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
-            u64 mask = Mw[0].mu | Mw[0].mi | Mw[0].mj;
-            if (mask) {
+            if (anyw[0] != 0ull) {
+                const mfcd_sample rk = load_rec(k);
+                const Masks M0 = role_masks(rk);
                 const int64_t pos0 = (int64_t)k * a.B;
-                const float inv_batch = 1.0f / (float)bsize(k);
+                const int bk = (N32 - k * a.B) < a.B ? (N32 - k * a.B) : a.B;
+                const float inv_batch = 1.0f / (float)bk;
+                u64 mask = M0.mu | M0.mi | M0.mj;
                 while (mask) {
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    if (!process_hit(sample_of(k, tl), Mw[0], tl, pos0 + tl, (unsigned)k + 1u, inv_batch)) return;
+                    if (!process_hit(lane_sample(rk, tl), M0, tl, pos0 + tl, (unsigned)k + 1u, inv_batch)) return;
                 }
             }
             [[maybe_unused]] const u64 t_adam0 = STAMP();
 #pragma unroll
-            for (int q = 0; q < Q; ++q) adam_update(p[q], m1[q], m2[q], gr[q], a.ac, sc_cur);
+            for (int q = 0; q < Q; ++q) adam_update_t<FAST>(p[q], m1[q], m2[q], gr[q], a.ac, sc_cur);
             [[maybe_unused]] const u64 t_adam1 = STAMP();
             DBG_ADD(3, t_adam1 - t_adam0);
             publish_phase(k, false);
@@ -384,7 +424,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                 }
             }
 #pragma unroll
-            for (int q = 0; q < Q; ++q) adam_update(p[q], m1[q], m2[q], gr[q], a.ac, sc);
+            for (int q = 0; q < Q; ++q) adam_update_t<FAST>(p[q], m1[q], m2[q], gr[q], a.ac, sc);
             if (k + 1 < a.K) publish(k + 1);
         }
     }

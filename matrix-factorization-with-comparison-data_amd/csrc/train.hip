@@ -282,6 +282,8 @@ StepScalars step_scalars(double lr, double beta1, double beta2, int64_t step)
     StepScalars s;
     s.neg_step_size = (float)(-(lr / bc1));
     s.bc2_sqrt = (float)sqrt(bc2);
+    s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    s.pad = 0.0f;
     return s;
 }
 
@@ -406,6 +408,13 @@ extern "C" int mfcd_set_train_path(int mode)
 {
     if (mode < 0 || mode > 2) return MFCD_EINVAL;
     g_train_path = mode;
+    return 0;
+}
+
+extern "C" int mfcd_set_resident_math(int fast)
+{
+    if (fast != 0 && fast != 1) return MFCD_EINVAL;
+    mfcd_detail::g_resident_math = fast;
     return 0;
 }
 

@@ -15,6 +15,8 @@ struct AdamStatic {
 struct StepScalars {
     float neg_step_size;  // -(lr / (1 - beta1^t))
     float bc2_sqrt;       // sqrt(1 - beta2^t)
+    float inv_bc2_sqrt;   // 1 / sqrt(1 - beta2^t), rounded from f64 (used by the fast flavour only)
+    float pad;
 };
 
 // One element of torch.optim.Adam's single-tensor step (coupled L2).  The operation sequence is pinned
@@ -38,12 +40,50 @@ __device__ __forceinline__ void adam_update(float &p, float &m1, float &m2, floa
     p = p + num / den;
 }
 
+// Fast flavour of the same update for the register-resident kernel, where the step is bound by VALU cycles:
+// identical op order, but the square root is the hardware v_sqrt_f32 (<= 1 ulp) and the two divisions are a
+// reciprocal multiply with one Newton correction of the quotient (q = q0 + (a - b*q0)*r, <= 1 ulp, almost always
+// the correctly rounded quotient) instead of the ~52-cycle IEEE expansions.  The update term therefore differs
+// from the IEEE flavour by at most a few ulp (~1e-10 absolute per step at lr = 1e-3).
+__device__ __forceinline__ float div_newton(float a, float b, float r /* ~ 1/b */)
+{
+#pragma clang fp contract(off)
+    const float q0 = a * r;
+    const float e = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(e, r, q0);
+}
+
+__device__ __forceinline__ void adam_update_fast(float &p, float &m1, float &m2, float gsparse, const AdamStatic &ac,
+                                                 const StepScalars &sc)
+{
+#pragma clang fp contract(off)
+    const float g = __builtin_fmaf(ac.wd, p, gsparse);
+    m1 = __builtin_fmaf(ac.w1, g - m1, m1);
+    const float v_scaled = m2 * ac.b2;
+    const float gg = (ac.w2 * g) * g;
+    m2 = v_scaled + gg;
+    const float sq = __builtin_amdgcn_sqrtf(m2);
+    const float den = div_newton(sq, sc.bc2_sqrt, sc.inv_bc2_sqrt) + ac.eps;
+    const float num = sc.neg_step_size * m1;
+    p = p + div_newton(num, den, __builtin_amdgcn_rcpf(den));
+}
+
+template <bool FAST>
+__device__ __forceinline__ void adam_update_t(float &p, float &m1, float &m2, float gsparse, const AdamStatic &ac,
+                                              const StepScalars &sc)
+{
+    if constexpr (FAST) adam_update_fast(p, m1, m2, gsparse, ac, sc);
+    else adam_update(p, m1, m2, gsparse, ac, sc);
+}
+
 namespace mfcd_detail {
 
 struct ResidentPlan {
     bool ok;
     int Q, NW, blocks;
 };
+
+extern int g_resident_math;
 
 ResidentPlan plan_resident(int n, int m, int d, int num_cus);
 

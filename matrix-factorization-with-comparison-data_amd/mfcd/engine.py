@@ -125,6 +125,11 @@ def set_train_path(mode):
     _lib.check(_lib.load().mfcd_set_train_path(TRAIN_PATHS[mode]))
 
 
+def set_resident_math(flavour):
+    """Adam arithmetic inside the resident form: "fast" (default) or "ieee" (include/mfcd.h)."""
+    _lib.check(_lib.load().mfcd_set_resident_math({"ieee": 0, "fast": 1}[flavour]))
+
+
 def check_status():
     """Raise if the last resident launch gave up on a bounded wait (workspace status word). Synchronises."""
     if _ws.buf is not None:

@@ -32,13 +32,17 @@ def resident_applies(n, m, d):
     return 2 <= d <= 256 and (d & (d - 1)) == 0 and (n + m) * d <= 256 * 8 * 64 * 16
 
 
-@pytest.fixture(params=["streaming", "resident"])
+@pytest.fixture(params=["streaming", "resident", "resident-ieee"])
 def path(request, dev):
-    """Run a training test once per form of the fused step (include/mfcd.h, mfcd_set_train_path)."""
+    """Run a training test once per form of the fused step (include/mfcd.h: mfcd_set_train_path), the resident form
+    in both arithmetic flavours (mfcd_set_resident_math: fast is the default)."""
     from mfcd import engine
-    engine.set_train_path(request.param)
-    yield request.param
+    form = request.param.split("-")[0]
+    engine.set_train_path(form)
+    engine.set_resident_math("ieee" if request.param.endswith("ieee") else "fast")
+    yield form
     engine.set_train_path("auto")
+    engine.set_resident_math("fast")
 
 
 def _model_from(U0, V0, dev, lr, wd):
