@@ -250,7 +250,7 @@ def _run():
 
     from mfcd import _lib
     plan_resident = (cfg["d"] & (cfg["d"] - 1)) == 0 and 2 <= cfg["d"] <= 256 and (cfg["n"] + cfg["m"]) * cfg["d"] <= 2097152
-    kernel_name = ("resident_train_kernel<D=64,Q=4,B<=64> (persistent: one launch per epoch; figures are per optimiser "
+    kernel_name = ("resident_train_kernel<D=64,Q=2,LOOK=4,fast> (persistent: one launch per epoch; figures are per optimiser "
                    "step = launch time / steps)") if plan_resident else "train_step_kernel (one launch per optimiser step)"
     launches = sum(k for _, _, k in runner.train_events)
     train_ms = sum(a.elapsed_time(b) for a, b, _ in runner.train_events)

@@ -58,8 +58,8 @@ static ResidentLauncher launcher_for(int d)
 
 // Resident-path plan: Q registers per array, NW owner waves, or ok=false when the path does not apply.
 // Every wave of the grid must be resident at once (waves wait on each other), so the wave count is bounded
-// by 2 workgroups of 4 waves per CU, which every instantiation's register allocation admits
-// (kernel-resource-usage: Q=1 ~70, Q=4 ~85, Q=16 ~176 VGPRs -> >= 2 waves per SIMD).
+// by what every instantiation's register allocation admits per CU (kernel-resource-usage: Q<=2 ~70 VGPRs ->
+// 4 workgroups of 4 waves; Q=4 ~85, Q=16 ~176 VGPRs -> 2 workgroups of 4 waves).
 ResidentPlan plan_resident(int n, int m, int d, int num_cus)
 {
     ResidentPlan pl{};
@@ -69,12 +69,16 @@ ResidentPlan plan_resident(int n, int m, int d, int num_cus)
     // tuning override for experiments (tools/): MFCD_RESIDENT_Q forces the slice size
     const char *eq = getenv("MFCD_RESIDENT_Q");
     const int forced_q = eq ? atoi(eq) : 0;
-    static const int kQ[3] = {1, 4, 16};
-    for (int qi = 0; qi < 3; ++qi) {
+    // Q <= 2 (<= ~70 VGPRs): 4 workgroups of 4 waves per CU are resident and hide each other's hand-off
+    // latency (measured +7 % at C2 over 2 per CU); larger slices stay at 2 workgroups per CU.
+    const char *ew = getenv("MFCD_RESIDENT_WPC");   // experiment knob: waves per CU bound for Q <= 2 (8 or 16)
+    const int wpc = ew ? atoi(ew) : 16;
+    static const int kQ[4] = {1, 2, 4, 16};
+    for (int qi = 0; qi < 4; ++qi) {
         const int Q = kQ[qi];
         if ((64 * Q) % d != 0 || (forced_q && Q != forced_q)) continue;
         const int64_t nw = (T + 64 * (int64_t)Q - 1) / (64 * Q);
-        if (nw <= (int64_t)num_cus * 8) {
+        if (nw <= (int64_t)num_cus * (Q <= 2 ? wpc : 8)) {
             pl.ok = true;
             pl.Q = Q;
             pl.NW = (int)nw;
@@ -97,8 +101,10 @@ int launch_resident_steps(const ResidentPlan &pl, float *U, float *V, float *mU,
     a.N = N; a.B = B; a.n = n; a.m = m; a.K = K; a.NW = pl.NW; a.ac = ac;
     const char *la = getenv("MFCD_RESIDENT_LOOKAHEAD");  // tuning/test override: 0 disables look-ahead publishing
     a.lookahead = la ? atoi(la) : 4;
-    if (N + 64 * 8 >= ((int64_t)1 << 31)) a.lookahead = 0;   // the look-ahead form indexes samples with 32 bits
+    if (N + 64 * 16 >= ((int64_t)1 << 31)) a.lookahead = 0;   // the look-ahead form indexes samples with 32 bits
     a.fast_math = g_resident_math;
+    const char *lp = getenv("MFCD_RESIDENT_LDS_PAD");   // experiment knob (bytes)
+    a.lds_pad = lp ? atoi(lp) : 0;
     ResidentLauncher fn = launcher_for(d);
     if (!fn) return MFCD_EINVAL;
     return fn(&a, pl.Q, pl.blocks, (void *)st);

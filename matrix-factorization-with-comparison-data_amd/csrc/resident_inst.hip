@@ -1,5 +1,5 @@
 // resident_inst.hip — instantiations of the resident kernel for ONE factor width (-DMFCD_RES_D=<d>), so the
-// widths build in parallel.  Slice sizes: Q in {1, 4, 16} registers per array (64..1024 elements per wave).
+// widths build in parallel.  Slice sizes: Q in {1, 2, 4, 16} registers per array (64..1024 elements per wave).
 #include "resident_kernel.h"
 
 #ifndef MFCD_RES_D
@@ -16,8 +16,10 @@ bool launch_q(const mfcd_detail::ResidentArgs &a, int blocks, hipStream_t st)
     if constexpr ((64 * Q) % D == 0) {
         const bool look = a.B <= 64 && a.lookahead > 0;
 #define MFCD_LAUNCH(L, F) \
-    hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, L, F>), dim3(blocks), dim3(256), 0, st, a)
-        if (look && a.fast_math) MFCD_LAUNCH(4, true);
+    hipLaunchKernelGGL((mfcd_detail::resident_train_kernel<D, Q, L, F>), dim3(blocks), dim3(256), a.lds_pad, st, a)
+        if (look && a.lookahead >= 8 && a.fast_math) MFCD_LAUNCH(8, true);
+        else if (look && a.lookahead >= 8) MFCD_LAUNCH(8, false);
+        else if (look && a.fast_math) MFCD_LAUNCH(4, true);
         else if (look) MFCD_LAUNCH(4, false);
         else if (a.fast_math) MFCD_LAUNCH(0, true);
         else MFCD_LAUNCH(0, false);
@@ -37,6 +39,7 @@ extern "C" int MFCD_CAT(mfcd_resident_launch_d, MFCD_RES_D)(const mfcd_detail::R
     bool ok = false;
     switch (Q) {
         case 1: ok = launch_q<MFCD_RES_D, 1>(*a, blocks, st); break;
+        case 2: ok = launch_q<MFCD_RES_D, 2>(*a, blocks, st); break;
         case 4: ok = launch_q<MFCD_RES_D, 4>(*a, blocks, st); break;
         case 16: ok = launch_q<MFCD_RES_D, 16>(*a, blocks, st); break;
         default: break;

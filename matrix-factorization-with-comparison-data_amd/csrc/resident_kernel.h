@@ -46,6 +46,7 @@ struct ResidentArgs {
     int B, n, m, K, NW;
     int lookahead;           // 0: publish right before use (any B); >0: look-ahead form (B <= 64)
     int fast_math;           // Adam arithmetic flavour: 0 IEEE-rounded, 1 v_sqrt / Newton-corrected rcp
+    int lds_pad;             // unused dynamic LDS per workgroup: caps workgroups per CU so placement is even
     AdamStatic ac;
 };
 
@@ -270,8 +271,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             r.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.z), tl));
             return r;
         };
-        auto touches = [&](int step, int R) {                      // does batch `step` touch global row R ?
-            const mfcd_sample s = load_rec(step);
+        auto touches = [&](const mfcd_sample &s, int R) {          // does the batch held in `s` touch global row R ?
             return __ballot(s.u == R || s.i + a.n == R || s.j + a.n == R) != 0ull;
         };
 
@@ -289,12 +289,16 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                 for (int b2 = 1; b2 < W; ++b2) cand |= anyw[b2];
             }
             if (cand == 0ull) return;                              // the common case
+            // slow path: bring the whole window's records in with ONE burst of independent loads
+            mfcd_sample wrec[W + 1];
+#pragma unroll
+            for (int b2 = 0; b2 <= W; ++b2) wrec[b2] = load_rec(j + b2 >= 0 ? j + b2 : a.K + 1);
 #pragma unroll
             for (int kk = 1; kk <= W; ++kk) {
                 const int k = j + kk;
                 if (anyw[kk] == 0ull || k >= a.K) continue;
                 if (kk < W && !first && anyw[0] == 0ull) continue; // none of my rows was touched by batch j
-                const mfcd_sample rk = load_rec(k);
+                const mfcd_sample rk = wrec[kk];
                 const Masks Mk = role_masks(rk);
                 u64 pm = Mk.mu | Mk.mi | Mk.mj;
                 while (pm) {
@@ -310,9 +314,9 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                         const int R = rows[r];
                         bool later_touch = false;   // a batch in (j, k) touches R -> published after that step instead
 #pragma unroll
-                        for (int b2 = 1; b2 < kk; ++b2) later_touch = later_touch || touches(j + b2, R);
+                        for (int b2 = 1; b2 < kk; ++b2) later_touch = later_touch | touches(wrec[b2], R);
                         if (later_touch) continue;
-                        if (kk < W && !first && !touches(j, R)) continue;  // already published when k entered the window
+                        if (kk < W && !first && !touches(wrec[0], R)) continue;  // already published when k entered the window
                         // roll the registers of row R forward over steps j+1 .. k-1 (dense-only updates)
                         const int q0 = reg_of(R);
                         float pp[S], mm1[S], mm2[S];

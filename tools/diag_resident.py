@@ -26,3 +26,12 @@ print(f"  hits total {hits} ({hits/K:.1f}/step); polls(spins) total {dbg[:,6].su
 print(f"  per hit: wait {dbg[:,1].sum()/hits:.0f} cyc, compute {dbg[:,2].sum()/hits:.0f} cyc")
 other = dbg[:, 0] - dbg[:, 1:5].sum(1)
 print(f"  other (scan, loop) mean {other.mean():.0f} cyc/wave = {100*other.mean()/dbg[:,0].mean():.1f}%; per step {other.mean()/K:.1f} cyc")
+
+import numpy as np
+w = dbg[:, 1] / dbg[:, 0]
+order = np.argsort(w)
+print("poll-wait share of wave time: min %.3f p10 %.3f median %.3f p90 %.3f max %.3f" % (w.min(), np.percentile(w,10), np.median(w), np.percentile(w,90), w.max()))
+for name, idx in (("least-waiting 20 waves", order[:20]), ("most-waiting 20 waves", order[-20:])):
+    sub = dbg[idx]
+    print(f"  {name}: hits/wave {sub[:,5].mean():.1f}  wait {sub[:,1].mean()/K:.0f} ticks/step  hit-compute {sub[:,2].mean()/K:.0f}  adam {sub[:,3].mean()/K:.0f}  publish {sub[:,4].mean()/K:.0f}  other {(sub[:,0]-sub[:,1:5].sum(1)).mean()/K:.0f}  total {sub[:,0].mean()/K:.0f}")
+print("hits per wave: min %d median %d max %d" % (dbg[:,5].min(), np.median(dbg[:,5]), dbg[:,5].max()))
