@@ -115,6 +115,20 @@ int mfcd_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float 
                      float *loss_per_step, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * bf16 factor storage (BASELINE.json configs[2]; the reference has no such mode, the rounding points are defined
+ * here and in oracle/mfcd_oracle.c): U [n][d], V [m][d] are bf16 in HBM; each step reads them as such, does all
+ * arithmetic and keeps the Adam moments in fp32, and rounds the updated parameters to the nearest bf16 (ties to
+ * even) once, when they are written back.  Always the streaming form; 20 bytes per element per step instead of 24.
+ */
+int mfcd_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, float *mV, float *vV,
+                          const mfcd_sample *samples, int64_t N, int B, int64_t step0, int n, int m,
+                          int d, double lr, double beta1, double beta2, double eps, double weight_decay,
+                          float *loss_per_step, void *workspace, size_t workspace_bytes, void *stream);
+int mfcd_eval_batches_bf16(const uint16_t *U, const uint16_t *V, const mfcd_sample *samples, int64_t N,
+                           int B, int n, int m, int d, float *loss_per_batch,
+                           int32_t *correct_per_batch, float *p_out, void *stream);
+
+/*
  * Diagnostic twin of mfcd_train_steps for bench.py's roofline figure: identical work, but every step
  * launch is bracketed by its own pair of HIP events on `stream`, and the call WAITS for the last one.
  * kernel_us_host[3] (HOST memory) receives the average / min / max step-kernel duration in microseconds.

@@ -72,12 +72,18 @@ __device__ __forceinline__ float bce_sigmoid_backward_f32(float p, float z, floa
     return a * (1.0f - p) * p;
 }
 
+// Factor tables are stored as fp32 or bf16 (BASELINE configs[2]: "bf16 factors"); arithmetic is always fp32.
+typedef __bf16 mfcd_bf16;
+__device__ __forceinline__ float ldf(const float *p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float ldf(const mfcd_bf16 *p, int64_t i) { return (float)p[i]; }
+
 // x_t = sum_k U[u][k] * (V[i][k] - V[j][k]) computed by one whole wave; all lanes return x_t.
-__device__ __forceinline__ float wave_score(const float *__restrict__ U, const float *__restrict__ V,
-                                            int u, int i, int j, int d, int lane)
+template <typename TP>
+__device__ __forceinline__ float wave_score(const TP *__restrict__ U, const TP *__restrict__ V, int u, int i, int j,
+                                            int d, int lane)
 {
-    const float *ur = U + (int64_t)u * d, *vi = V + (int64_t)i * d, *vj = V + (int64_t)j * d;
+    const TP *ur = U + (int64_t)u * d, *vi = V + (int64_t)i * d, *vj = V + (int64_t)j * d;
     float acc = 0.0f;
-    for (int k = lane; k < d; k += MFCD_WAVE) acc += ur[k] * (vi[k] - vj[k]);  // product rounded, then summed (torch.sum(u*(vi-vj)))
+    for (int k = lane; k < d; k += MFCD_WAVE) acc += ldf(ur, k) * (ldf(vi, k) - ldf(vj, k));  // product rounded, then summed
     return wave_sum64(acc);
 }

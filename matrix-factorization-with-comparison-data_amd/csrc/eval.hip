@@ -6,7 +6,8 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void eval_batches_kernel(const float *__restrict__ U, const float *__restrict__ V,
+template <typename TP>
+__global__ __launch_bounds__(256) void eval_batches_kernel(const TP *__restrict__ U, const TP *__restrict__ V,
                                                            const mfcd_sample *__restrict__ samples, int64_t N, int B,
                                                            int d, float *__restrict__ loss_per_batch,
                                                            int32_t *__restrict__ correct_per_batch,
@@ -57,18 +58,35 @@ __global__ __launch_bounds__(256) void check_samples_kernel(const mfcd_sample *_
 
 }  // namespace
 
-extern "C" int mfcd_eval_batches(const float *U, const float *V, const mfcd_sample *samples, int64_t N, int B, int n,
-                                 int m, int d, float *loss_per_batch, int32_t *correct_per_batch, float *p_out,
-                                 void *stream)
+namespace {
+template <typename TP>
+int eval_batches_impl(const TP *U, const TP *V, const mfcd_sample *samples, int64_t N, int B, int n, int m, int d,
+                      float *loss_per_batch, int32_t *correct_per_batch, float *p_out, void *stream)
 {
     if (!U || !V || n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D || N < 0 || B <= 0 || B > 16384) return MFCD_EINVAL;
     if (N == 0) return 0;
     if (!samples || !loss_per_batch) return MFCD_EINVAL;
     const int64_t nb = (N + B - 1) / B;
-    hipLaunchKernelGGL(eval_batches_kernel, dim3((unsigned)nb), dim3(256), sizeof(float) * 2 * (size_t)B,
+    hipLaunchKernelGGL((eval_batches_kernel<TP>), dim3((unsigned)nb), dim3(256), sizeof(float) * 2 * (size_t)B,
                        (hipStream_t)stream, U, V, samples, N, B, d, loss_per_batch, correct_per_batch, p_out);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" int mfcd_eval_batches(const float *U, const float *V, const mfcd_sample *samples, int64_t N, int B, int n,
+                                 int m, int d, float *loss_per_batch, int32_t *correct_per_batch, float *p_out,
+                                 void *stream)
+{
+    return eval_batches_impl<float>(U, V, samples, N, B, n, m, d, loss_per_batch, correct_per_batch, p_out, stream);
+}
+
+extern "C" int mfcd_eval_batches_bf16(const uint16_t *U, const uint16_t *V, const mfcd_sample *samples, int64_t N,
+                                      int B, int n, int m, int d, float *loss_per_batch, int32_t *correct_per_batch,
+                                      float *p_out, void *stream)
+{
+    return eval_batches_impl<mfcd_bf16>((const mfcd_bf16 *)U, (const mfcd_bf16 *)V, samples, N, B, n, m, d,
+                                        loss_per_batch, correct_per_batch, p_out, stream);
 }
 
 extern "C" int mfcd_check_samples(const mfcd_sample *samples, int64_t N, int n, int m, int32_t *bad_count_dev,

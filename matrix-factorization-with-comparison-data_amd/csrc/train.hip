@@ -51,6 +51,32 @@ __device__ __forceinline__ void load_vec(const float *p, float (&r)[VEC])
 }
 
 template <int VEC>
+__device__ __forceinline__ void load_vec(const mfcd_bf16 *p, float (&r)[VEC])
+{
+    if constexpr (VEC == 4) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);   // 4 bf16 = 8 bytes
+        r[0] = __uint_as_float(t.x << 16); r[1] = __uint_as_float(t.x & 0xffff0000u);
+        r[2] = __uint_as_float(t.y << 16); r[3] = __uint_as_float(t.y & 0xffff0000u);
+    } else {
+        r[0] = (float)*p;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(mfcd_bf16 *p, const float (&r)[VEC])
+{
+    if constexpr (VEC == 4) {   // round to nearest even, once per step (the defined rounding point)
+        const unsigned short b0 = __builtin_bit_cast(unsigned short, (mfcd_bf16)r[0]);
+        const unsigned short b1 = __builtin_bit_cast(unsigned short, (mfcd_bf16)r[1]);
+        const unsigned short b2 = __builtin_bit_cast(unsigned short, (mfcd_bf16)r[2]);
+        const unsigned short b3 = __builtin_bit_cast(unsigned short, (mfcd_bf16)r[3]);
+        *reinterpret_cast<uint2 *>(p) = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+    } else {
+        *p = (mfcd_bf16)r[0];
+    }
+}
+
+template <int VEC>
 __device__ __forceinline__ void store_vec(float *p, const float (&r)[VEC])
 {
     if constexpr (VEC == 4) {
@@ -64,10 +90,10 @@ __device__ __forceinline__ void store_vec(float *p, const float (&r)[VEC])
 // MODE 0: the fused step.  MODE 1 (data-parallel, before the all-reduce): only this rank's dense gradient,
 // Gu/Gv[e] = sum of the local samples' row gradients (no Adam, parameters untouched).  MODE 2 (after the
 // all-reduce): Adam from the dense gradient Gu/Gv, no batch scan.
-template <int VEC, int CHUNKS, int MODE = 0>
+template <int VEC, int CHUNKS, int MODE = 0, typename TP = float>
 __global__ __launch_bounds__(256) void train_step_kernel(
-    const float *__restrict__ Uin, const float *__restrict__ Vin, float *__restrict__ Uout,
-    float *__restrict__ Vout, float *__restrict__ mU, float *__restrict__ vU, float *__restrict__ mV,
+    const TP *__restrict__ Uin, const TP *__restrict__ Vin, TP *__restrict__ Uout,
+    TP *__restrict__ Vout, float *__restrict__ mU, float *__restrict__ vU, float *__restrict__ mV,
     float *__restrict__ vV, const mfcd_sample *__restrict__ batch, const float *__restrict__ g_in,
     int Bk, float inv_batch, int n, int m, int d, int blocksU, AdamConst ac,
     float *__restrict__ loss_terms, float *__restrict__ Gu, float *__restrict__ Gv)
@@ -85,8 +111,8 @@ __global__ __launch_bounds__(256) void train_step_kernel(
     const int row_hi = (int)((e1 + d - 1) / d);
     const int sg_off = (int)(e0 - (int64_t)row_lo * d);  // position of element e0 inside sg
 
-    const float *__restrict__ Pin = isV ? Vin : Uin;
-    float *__restrict__ Pout = isV ? Vout : Uout;
+    const TP *__restrict__ Pin = isV ? Vin : Uin;
+    TP *__restrict__ Pout = isV ? Vout : Uout;
     float *__restrict__ M1 = isV ? mV : mU;
     float *__restrict__ M2 = isV ? vV : vU;
     float *__restrict__ G = isV ? Gv : Gu;
@@ -141,14 +167,13 @@ __global__ __launch_bounds__(256) void train_step_kernel(
                 const int uu = __shfl(s.u, tl, MFCD_WAVE), ii = __shfl(s.i, tl, MFCD_WAVE),
                           jj = __shfl(s.j, tl, MFCD_WAVE);
                 const float zz = __shfl(s.z, tl, MFCD_WAVE);
-                const float *ur = Uin + (int64_t)uu * d, *vi = Vin + (int64_t)ii * d,
-                            *vj = Vin + (int64_t)jj * d;
+                const TP *ur = Uin + (int64_t)uu * d, *vi = Vin + (int64_t)ii * d, *vj = Vin + (int64_t)jj * d;
                 float g;
                 if (g_in) {
                     g = g_in[base + tl];
                 } else {
                     float acc = 0.0f;
-                    for (int k = lane; k < d; k += MFCD_WAVE) acc += ur[k] * (vi[k] - vj[k]);
+                    for (int k = lane; k < d; k += MFCD_WAVE) acc += ldf(ur, k) * (ldf(vi, k) - ldf(vj, k));
                     const float p = sigmoid_f32(wave_sum64(acc));
                     g = bce_sigmoid_backward_f32(p, zz, inv_batch);
                     // the workgroup that owns the first element of row u records the loss term
@@ -159,15 +184,15 @@ __global__ __launch_bounds__(256) void train_step_kernel(
                 }
                 if ((mu >> tl) & 1ull) {
                     float *dst = sg + (int64_t)(uu - row_lo) * d;
-                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += g * (vi[k] - vj[k]);
+                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += g * (ldf(vi, k) - ldf(vj, k));
                 }
                 if ((mi >> tl) & 1ull) {
                     float *dst = sg + (int64_t)(ii - row_lo) * d;
-                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += g * ur[k];
+                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += g * ldf(ur, k);
                 }
                 if ((mj >> tl) & 1ull) {
                     float *dst = sg + (int64_t)(jj - row_lo) * d;
-                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += -(g * ur[k]);
+                    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] += -(g * ldf(ur, k));
                 }
             }
         }
@@ -295,26 +320,26 @@ AdamConst adam_const(double lr, double beta1, double beta2, double eps, double w
     return ac;
 }
 
-template <int VEC, int CHUNKS, int MODE>
-void launch_step(const Plan &pl, hipStream_t st, const float *Uin, const float *Vin, float *Uout, float *Vout,
+template <int VEC, int CHUNKS, int MODE, typename TP>
+void launch_step(const Plan &pl, hipStream_t st, const TP *Uin, const TP *Vin, TP *Uout, TP *Vout,
                  float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
                  float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu, float *Gv)
 {
-    hipLaunchKernelGGL((train_step_kernel<VEC, CHUNKS, MODE>), dim3(pl.blocksU + pl.blocksV), dim3(256), pl.lds, st,
+    hipLaunchKernelGGL((train_step_kernel<VEC, CHUNKS, MODE, TP>), dim3(pl.blocksU + pl.blocksV), dim3(256), pl.lds, st,
                        Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, m, d, pl.blocksU, ac,
                        loss_terms, Gu, Gv);
 }
 
-template <int MODE = 0>
-void dispatch_step(const Plan &pl, hipStream_t st, const float *Uin, const float *Vin, float *Uout, float *Vout,
+template <int MODE = 0, typename TP = float>
+void dispatch_step(const Plan &pl, hipStream_t st, const TP *Uin, const TP *Vin, TP *Uout, TP *Vout,
                    float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
                    float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu = nullptr,
                    float *Gv = nullptr)
 {
 #define MFCD_CASE(V, C)                                                                                              \
     if (pl.vec == V && pl.chunks == C)                                                                               \
-        return launch_step<V, C, MODE>(pl, st, Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, \
-                                       m, d, ac, loss_terms, Gu, Gv);
+        return launch_step<V, C, MODE, TP>(pl, st, Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, \
+                                           n, m, d, ac, loss_terms, Gu, Gv);
     MFCD_CASE(4, 1) MFCD_CASE(4, 2) MFCD_CASE(4, 4) MFCD_CASE(4, 8)
     MFCD_CASE(1, 1) MFCD_CASE(1, 2) MFCD_CASE(1, 4) MFCD_CASE(1, 8)
 #undef MFCD_CASE
@@ -433,7 +458,8 @@ namespace {
 
 // Shared body of mfcd_train_steps / mfcd_train_steps_timed.  With `timing_us` set, every step launch is
 // bracketed by its own pair of HIP events on the launch stream and the host waits for them at the end.
-int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *samples,
+template <typename TP>
+int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *samples,
                     int64_t N, int B, int64_t step0, int n, int m, int d, double lr, double beta1, double beta2,
                     double eps, double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
                     void *stream, float *timing_us)
@@ -449,9 +475,10 @@ int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *
     MFCD_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
 
     mfcd_detail::ResidentPlan rp;
-    const bool resident = resident_applies(N, B, n, m, d, &rp);
+    constexpr bool kF32 = sizeof(TP) == 4;   // the resident form holds fp32 state; bf16 factors use the streaming form
+    const bool resident = kF32 && resident_applies(N, B, n, m, d, &rp);
     if (g_train_path == 2 && !resident) return MFCD_EINVAL;
-    if (resident) {
+    if constexpr (kF32) if (resident) {
         // ---- persistent register-resident form: ONE launch for all nsteps (resident.hip) ----
         if (nsteps > 0x7fffffff) return MFCD_EINVAL;
         const ResidentLayout L = resident_layout(N, B, d);
@@ -480,7 +507,7 @@ int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *
             MFCD_HIP_TRY(hipEventCreate(&e1));
             MFCD_HIP_TRY(hipEventRecord(e0, st));
         }
-        if (int rc = mfcd_detail::launch_resident_steps(rp, U, V, mU, vU, mV, vV, samples, N, B, n, m, d, sc_dev,
+        if (int rc = mfcd_detail::launch_resident_steps(rp, (float *)U, (float *)V, mU, vU, mV, vV, samples, N, B, n, m, d, sc_dev,
                                                        adam_static(beta1, beta2, eps, weight_decay), mailbox, terms_r,
                                                        status, (unsigned long long *)(base + L.dbg_off), (int)nsteps,
                                                        st))
@@ -504,9 +531,9 @@ int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *
 
     // ---- streaming form: one launch per optimiser step ----
     char *ws = (char *)workspace + kStatusBytes;
-    float *Ualt = (float *)ws;
+    TP *Ualt = (TP *)ws;
     ws += align256(sizeof(float) * (size_t)n * d);
-    float *Valt = (float *)ws;
+    TP *Valt = (TP *)ws;
     ws += align256(sizeof(float) * (size_t)m * d);
     float *terms = (float *)ws;
 
@@ -523,14 +550,14 @@ int run_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *
         const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step0 + k + 1);
         const bool even = (k & 1) == 0;
         if (timing_us) MFCD_HIP_TRY(hipEventRecord(ev[2 * k], st));
-        dispatch_step(pl, st, even ? U : Ualt, even ? V : Valt, even ? Ualt : U, even ? Valt : V, mU, vU, mV, vV,
-                      samples + off, nullptr, Bk, 1.0f / (float)Bk, n, m, d, ac, terms + off);
+        dispatch_step<0, TP>(pl, st, even ? U : Ualt, even ? V : Valt, even ? Ualt : U, even ? Valt : V, mU, vU, mV, vV,
+                             samples + off, nullptr, Bk, 1.0f / (float)Bk, n, m, d, ac, terms + off);
         if (timing_us) MFCD_HIP_TRY(hipEventRecord(ev[2 * k + 1], st));
     }
     MFCD_HIP_TRY(hipGetLastError());
     if (nsteps & 1) {
-        MFCD_HIP_TRY(hipMemcpyAsync(U, Ualt, sizeof(float) * (size_t)n * d, hipMemcpyDeviceToDevice, st));
-        MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(float) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
+        MFCD_HIP_TRY(hipMemcpyAsync(U, Ualt, sizeof(TP) * (size_t)n * d, hipMemcpyDeviceToDevice, st));
+        MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(TP) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
     }
     if (loss_per_step) {
         hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms,
@@ -563,8 +590,18 @@ extern "C" int mfcd_train_steps(float *U, float *V, float *mU, float *vU, float 
                                 double lr, double beta1, double beta2, double eps, double weight_decay,
                                 float *loss_per_step, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return run_train_steps(U, V, mU, vU, mV, vV, samples, N, B, step0, n, m, d, lr, beta1, beta2, eps, weight_decay,
-                           loss_per_step, workspace, workspace_bytes, stream, nullptr);
+    return run_train_steps<float>(U, V, mU, vU, mV, vV, samples, N, B, step0, n, m, d, lr, beta1, beta2, eps,
+                                  weight_decay, loss_per_step, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int mfcd_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, float *mV, float *vV,
+                                     const mfcd_sample *samples, int64_t N, int B, int64_t step0, int n, int m, int d,
+                                     double lr, double beta1, double beta2, double eps, double weight_decay,
+                                     float *loss_per_step, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return run_train_steps<mfcd_bf16>((mfcd_bf16 *)U, (mfcd_bf16 *)V, mU, vU, mV, vV, samples, N, B, step0, n, m, d, lr,
+                                      beta1, beta2, eps, weight_decay, loss_per_step, workspace, workspace_bytes, stream,
+                                      nullptr);
 }
 
 extern "C" int mfcd_train_steps_timed(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
@@ -574,8 +611,8 @@ extern "C" int mfcd_train_steps_timed(float *U, float *V, float *mU, float *vU, 
                                       float *kernel_us_host)
 {
     if (!kernel_us_host) return MFCD_EINVAL;
-    return run_train_steps(U, V, mU, vU, mV, vV, samples, N, B, step0, n, m, d, lr, beta1, beta2, eps, weight_decay,
-                           loss_per_step, workspace, workspace_bytes, stream, kernel_us_host);
+    return run_train_steps<float>(U, V, mU, vU, mV, vV, samples, N, B, step0, n, m, d, lr, beta1, beta2, eps,
+                                  weight_decay, loss_per_step, workspace, workspace_bytes, stream, kernel_us_host);
 }
 
 extern "C" int mfcd_batch_coefficients(const float *U, const float *V, const mfcd_sample *samples, int B, int n,
@@ -625,8 +662,9 @@ extern "C" int mfcd_dense_grad(const float *U, const float *V, const mfcd_sample
     const void *ptrs[] = {U, V, gradU, gradV};
     const Plan pl = make_plan(ptrs, 4, n, m, d);
     AdamConst ac{};
-    dispatch_step<1>(pl, (hipStream_t)stream, U, V, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, samples,
-                     nullptr, B, 1.0f / (float)batch_divisor, n, m, d, ac, term_out, gradU, gradV);
+    dispatch_step<1, float>(pl, (hipStream_t)stream, U, V, (float *)nullptr, (float *)nullptr, nullptr, nullptr, nullptr,
+                            nullptr, samples, nullptr, B, 1.0f / (float)batch_divisor, n, m, d, ac, term_out, gradU,
+                            gradV);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }

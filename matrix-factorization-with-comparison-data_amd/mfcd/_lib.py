@@ -23,6 +23,8 @@ SIGNATURES = {
     "mfcd_set_train_path": (_i32, [_i32]),
     "mfcd_set_resident_math": (_i32, [_i32]),
     "mfcd_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp, _sz, _vp]),
+    "mfcd_train_steps_bf16": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp, _sz, _vp]),
+    "mfcd_eval_batches_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfcd_train_steps_timed": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
                                [_vp, _vp, _sz, _vp, _vp]),
     "mfcd_batch_coefficients": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -11,12 +11,15 @@ from . import _lib
 from .batching import dataset_records, epoch_order, n_batches, pack_records
 
 
-def _require_cuda_param(t, name):
+def _require_cuda_param(t, name, dtypes=(torch.float32,)):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.MfcdError(f"{name} must live on a GPU device: the triplet hot path is MI355X-only "
                              "(pass device='cuda'; there is no CPU fallback)")
-    if t.dtype != torch.float32 or not t.is_contiguous():
-        raise _lib.MfcdError(f"{name} must be a contiguous float32 tensor")
+    if t.dtype not in dtypes or not t.is_contiguous():
+        raise _lib.MfcdError(f"{name} must be a contiguous tensor of dtype {' or '.join(str(x) for x in dtypes)}")
+
+
+_FACTOR_DTYPES = (torch.float32, torch.bfloat16)
 
 
 class AdamBinding:
@@ -37,16 +40,18 @@ class AdamBinding:
         if len(params) != 2 or not any(p is model.U for p in params) or not any(p is model.V for p in params):
             raise NotImplementedError("the optimizer must hold exactly model.U and model.V")
         self.model, self.opt, self.group = model, optimizer, g
-        _require_cuda_param(model.U.data, "model.U")
-        _require_cuda_param(model.V.data, "model.V")
+        _require_cuda_param(model.U.data, "model.U", _FACTOR_DTYPES)
+        _require_cuda_param(model.V.data, "model.V", _FACTOR_DTYPES)
         if model.U.shape[1] != model.V.shape[1]:
             raise ValueError("U and V must share the latent dimension")
-        for p in (model.U, model.V):  # lazily created exactly as Adam._init_group does
-            st = optimizer.state[p]
+        if model.U.dtype != model.V.dtype:
+            raise ValueError("U and V must share the storage dtype")
+        for p in (model.U, model.V):  # lazily created as Adam._init_group does — except that the moments are
+            st = optimizer.state[p]   # always fp32 (bf16 factors keep fp32 exp_avg / exp_avg_sq: SURVEY section 7(8))
             if len(st) == 0:
                 st["step"] = torch.tensor(0.0, dtype=torch.get_default_dtype())
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
             _require_cuda_param(st["exp_avg"], "exp_avg")
             _require_cuda_param(st["exp_avg_sq"], "exp_avg_sq")
         su, sv = optimizer.state[model.U]["step"], optimizer.state[model.V]["step"]
@@ -158,7 +163,11 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None)
     args = [_lib.ptr(U), _lib.ptr(V), _lib.ptr(mU), _lib.ptr(vU), _lib.ptr(mV), _lib.ptr(vV),
             _lib.ptr(samples_dev), N, batch_size, binding.step, n, m, d, lr, b1, b2, eps, wd,
             _lib.ptr(loss_out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(U.device)]
-    if kernel_us is None:
+    if U.dtype == torch.bfloat16:
+        if kernel_us is not None:
+            raise NotImplementedError("the timed diagnostic twin exists for fp32 factors only")
+        _lib.check(L.mfcd_train_steps_bf16(*args))
+    elif kernel_us is None:
         _lib.check(L.mfcd_train_steps(*args))
     else:
         out = (ctypes.c_float * 3)()
@@ -171,15 +180,16 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None)
 def eval_batches(U, V, samples_dev, batch_size, want_p=False):
     """Forward + BCE per batch.  Returns (loss_per_batch fp32, correct_per_batch int32, p or None), on device."""
     L = _lib.load()
-    _require_cuda_param(U, "U")
-    _require_cuda_param(V, "V")
+    _require_cuda_param(U, "U", _FACTOR_DTYPES)
+    _require_cuda_param(V, "V", _FACTOR_DTYPES)
     (n, d), m = U.shape, V.shape[0]
     N = samples_dev.shape[0]
     nb = n_batches(N, batch_size)
+    fn = L.mfcd_eval_batches_bf16 if U.dtype == torch.bfloat16 else L.mfcd_eval_batches
     loss = torch.empty(max(nb, 1), dtype=torch.float32, device=U.device)
     corr = torch.empty(max(nb, 1), dtype=torch.int32, device=U.device)
     p = torch.empty(max(N, 1), dtype=torch.float32, device=U.device) if want_p else None
-    _lib.check(L.mfcd_eval_batches(_lib.ptr(U), _lib.ptr(V), _lib.ptr(samples_dev), N, batch_size, n, m, d,
+    _lib.check(fn(_lib.ptr(U), _lib.ptr(V), _lib.ptr(samples_dev), N, batch_size, n, m, d,
                                    _lib.ptr(loss), _lib.ptr(corr), _lib.ptr(p), _lib.stream_ptr(U.device)))
     return loss[:nb], corr[:nb], (p[:N] if want_p else None)
 

@@ -27,6 +27,8 @@ def _workspace(nbytes, device):
 def uvt_stats(U, V, X, s=1.0):
     """→ (row_stats f64 [n,8] on device, scal f64 [4] on device); layout in include/mfcd.h."""
     L = _lib.load()
+    if U.dtype == torch.bfloat16:   # bf16 factors: exact widening for the one-off metric pass
+        U, V = U.float(), V.float()
     for t, nm in ((U, "U"), (V, "V"), (X, "X")):
         if not t.is_cuda or t.dtype != torch.float32:
             raise _lib.MfcdError(f"{nm} must be a float32 GPU tensor (no CPU fallback)")
@@ -45,7 +47,7 @@ def uvt_stats(U, V, X, s=1.0):
 def uvt_rows(U, V, row_ids):
     """Rows `row_ids` of UV^T as a [k, m] fp32 device tensor (structure.py:389-392 without the full GEMM)."""
     L = _lib.load()
-    U, V = U.contiguous(), V.contiguous()
+    U, V = U.float().contiguous(), V.float().contiguous()
     ids = torch.as_tensor(row_ids, dtype=torch.int32).to(U.device).contiguous()
     k, m = ids.numel(), V.shape[0]
     out = torch.empty((k, m), dtype=torch.float32, device=U.device)
@@ -115,6 +117,8 @@ def spearman_and_svd(U, V, X_centred_rows_mean, X, alpha, ok_rows, row_block=204
 
 def alpha_and_norm_ratios(U, V, X):
     """compute_alpha_and_norm_ratios (structure.py:958-1082) → the same 14-tuple."""
+    if U.dtype == torch.bfloat16:
+        U, V = U.float(), V.float()
     row_stats, _ = uvt_stats(U, V, X, 1.0)
     rs = row_stats.cpu().numpy()
     n, m = X.shape

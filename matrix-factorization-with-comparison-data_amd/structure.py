@@ -42,11 +42,13 @@ class MatrixFactorization(nn.Module):
     Calling the module evaluates the forward kernel (no autograd graph: training goes through
     `train_model`, which fuses backward and Adam on the device)."""
 
-    def __init__(self, n_users, n_items, d):
+    def __init__(self, n_users, n_items, d, dtype=torch.float32):
+        """`dtype=torch.bfloat16` (extension, BASELINE configs[2]) stores the factors in bf16: same fp32 draws,
+        rounded to nearest even; training then keeps fp32 Adam moments and rounds once per step."""
         super().__init__()
         scale = torch.sqrt(torch.tensor(d, dtype=torch.float32))
-        self.U = nn.Parameter(torch.randn(n_users, d) / scale)
-        self.V = nn.Parameter(torch.randn(n_items, d) / scale)
+        self.U = nn.Parameter((torch.randn(n_users, d) / scale).to(dtype))
+        self.V = nn.Parameter((torch.randn(n_items, d) / scale).to(dtype))
 
     def forward(self, u, i, j):
         U, V = self.U.data, self.V.data

@@ -62,6 +62,9 @@ class COracle:
                                                         ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
             [ctypes.c_double] * 5 + [_f32p, ctypes.c_int]
         L.mfcd_orc_train_steps.restype = ctypes.c_int
+        L.mfcd_orc_train_steps_bf16.argtypes = L.mfcd_orc_train_steps.argtypes
+        L.mfcd_orc_train_steps_bf16.restype = ctypes.c_int
+        L.mfcd_orc_round_bf16.argtypes = [_f32p, ctypes.c_int64]
         L.mfcd_orc_eval_batches.argtypes = [_f32p, _f32p, _i64p, _i64p, _i64p, _f32p, ctypes.c_int64, ctypes.c_int,
                                             ctypes.c_int, _f32p, _i32p, _f32p]
         L.mfcd_orc_eval_batches.restype = ctypes.c_int
@@ -99,9 +102,16 @@ class COracle:
         self.L.mfcd_orc_adam(_p(p, _f32p), _p(m, _f32p), _p(v, _f32p), _p(g, _f32p), p.size, lr, betas[0], betas[1],
                              eps, wd, float(step), threads)
 
-    def train_steps(self, state, u, i, j, z, B, step0, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, wd=0.0, threads=1):
+    def round_bf16(self, a):
+        """In place: nearest-even rounding of a contiguous fp32 array to bf16-representable values."""
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+        self.L.mfcd_orc_round_bf16(_p(a, _f32p), a.size)
+        return a
+
+    def train_steps(self, state, u, i, j, z, B, step0, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, wd=0.0, threads=1,
+                    bf16_factors=False):
         """state = dict(U,V,mU,vU,mV,vV) of contiguous fp32 arrays, updated in place.
-        → fp32 array of per-step batch-mean losses."""
+        → fp32 array of per-step batch-mean losses.  bf16_factors: U, V are rounded to bf16 after every step."""
         u, i, j, z = _i64(u), _i64(i), _i64(j), _f32(z)
         N = len(u)
         n, d = state["U"].shape
@@ -110,7 +120,8 @@ class COracle:
         losses = np.empty(nsteps, np.float32)
         for k in ("U", "V", "mU", "vU", "mV", "vV"):
             assert state[k].dtype == np.float32 and state[k].flags.c_contiguous
-        got = self.L.mfcd_orc_train_steps(
+        fn = self.L.mfcd_orc_train_steps_bf16 if bf16_factors else self.L.mfcd_orc_train_steps
+        got = fn(
             _p(state["U"], _f32p), _p(state["V"], _f32p), _p(state["mU"], _f32p), _p(state["vU"], _f32p),
             _p(state["mV"], _f32p), _p(state["vV"], _f32p), _p(u, _i64p), _p(i, _i64p), _p(j, _i64p), _p(z, _f32p),
             N, B, step0, n, m, d, lr, betas[0], betas[1], eps, wd, _p(losses, _f32p), threads)

@@ -508,3 +508,47 @@ def test_streaming_step_at_baseline_full_sizes(dev, orc, name, n, m, d, steps):
     np.testing.assert_allclose(outs[0][2].cpu().numpy(), ref_loss, rtol=2e-5, atol=2e-6)
     assert_close_with_rare_outliers(outs[0][0].cpu().numpy(), ref["U"], 2e-6, 1e-3, name + " U")
     assert_close_with_rare_outliers(outs[0][1].cpu().numpy(), ref["V"], 2e-6, 1e-3, name + " V")
+
+
+@pytest.mark.parametrize("n,m,d,steps", [(16384, 16384, 128, 24), (300, 200, 64, 60), (50, 40, 8, 40)])
+def test_bf16_factor_storage_matches_oracle_rounding_points(dev, orc, n, m, d, steps):
+    """BASELINE configs[2] ("bf16 factors"; first case = its shape): U, V stored as bf16, fp32 moments and arithmetic,
+    one round-to-nearest-even per step.  The reference has no such mode, so the ORACLE defines the rounding points
+    (parity unpinned by the reference).  A last-bit fp32 difference can flip a bf16 rounding, so the check is:
+    almost every element bit-equal, the rest within ONE bf16 ulp; losses within 1e-4 of the oracle and within 2e-2
+    of the fp32 run."""
+    from mfcd import engine
+    from oracle import oracle as O
+    import structure as S
+    B = 64
+    N = B * steps - 5
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=9 + d)
+    U0, V0 = orc.round_bf16(U0.copy()), orc.round_bf16(V0.copy())
+    st = _records(u, i, j, z, n, m, dev)
+    model = S.MatrixFactorization(n, m, d, dtype=torch.bfloat16)
+    with torch.no_grad():
+        model.U.copy_(torch.from_numpy(U0))
+        model.V.copy_(torch.from_numpy(V0))
+    model = model.to(dev)
+    assert model.U.dtype == torch.bfloat16 and torch.equal(model.U.data.float().cpu(), torch.from_numpy(U0))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    bind = engine.AdamBinding(model, opt)
+    assert opt.state[model.U]["exp_avg"].dtype == torch.float32
+    loss = engine.train_steps(bind, st.dev, B).cpu().numpy()
+    ref = O.new_state(U0, V0)
+    ref_loss = orc.train_steps(ref, u, i, j, z, B, 0, lr=1e-3, wd=1e-5, threads=8, bf16_factors=True)
+    np.testing.assert_allclose(loss, ref_loss, rtol=0, atol=1e-4)
+    for nm, got in (("U", model.U.data.float().cpu().numpy()), ("V", model.V.data.float().cpu().numpy())):
+        want = ref[nm]
+        diff = np.abs(got - want)
+        ulp = np.maximum(np.abs(want), 1e-30) * 2.0 ** -7          # >= one bf16 ulp of the value
+        assert (diff > 0).mean() < 2e-3, f"{nm}: {(diff > 0).mean():.2e} of the elements differ"
+        assert np.all(diff <= ulp), f"{nm}: an element differs by more than one bf16 ulp"
+    # eval pass on bf16 tables
+    vl, _, vp = engine.eval_batches(model.U.data, model.V.data, st.dev, B, want_p=True)
+    _, _, rp = orc.eval_batches(model.U.data.float().cpu().numpy(), model.V.data.float().cpu().numpy(), u, i, j, z, B)
+    np.testing.assert_allclose(vp.cpu().numpy(), rp, rtol=RTOL, atol=ATOL)
+    # against the fp32 run from the same (bf16-representable) start
+    f32 = O.new_state(U0, V0)
+    f32_loss = orc.train_steps(f32, u, i, j, z, B, 0, lr=1e-3, wd=1e-5, threads=8)
+    np.testing.assert_allclose(loss, f32_loss, rtol=0, atol=2e-2)

