@@ -36,13 +36,15 @@ class HipCompute:
         self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
         self.grad = None
 
-    def coefficients(self, rec_local, divisor):
-        """→ fp32 [2, B_local]: row 0 backward coefficients g_t (divisor = global batch), row 1 BCE terms."""
+    def coefficients(self, rec_local, divisor, out=None):
+        """→ fp32 [2, B_local]: row 0 backward coefficients g_t (divisor = global batch), row 1 BCE terms.
+        With `out` (a [2, >=B_local] fp32 buffer) the kernel writes in place and nothing is allocated."""
         U, V = self.b.model.U.data, self.b.model.V.data
         B = rec_local.shape[0]
-        out = torch.zeros((2, max(B, 1)), dtype=torch.float32, device=self.dev)
+        if out is None:
+            out = torch.zeros((2, max(B, 1)), dtype=torch.float32, device=self.dev)
         _lib.check(self.L.mfcd_batch_coefficients(_lib.ptr(U), _lib.ptr(V), _lib.ptr(rec_local), B, self.n, self.m,
-                                                  self.d, divisor, _lib.ptr(out[0]), _lib.ptr(out[1]), None,
+                                                  self.d, divisor, out[0].data_ptr(), out[1].data_ptr(), None,
                                                   _lib.stream_ptr(self.dev)))
         return out[:, :B]
 
@@ -86,42 +88,52 @@ def shard_bounds(global_lo, global_hi, batch_local, rank):
     return lo, hi
 
 
-def train_steps_dp(compute, stream, batch_local, mode="allgather", group=None, pad_record=None):
+def train_steps_dp(compute, stream, batch_local, mode="allgather", group=None):
     """Consume `stream` (records of the GLOBAL sample order, identical on every rank; [N,4] int32 tensor)
     in global batches of batch_local * world_size.  Returns a fp32 tensor with the global batch-mean loss of
-    every step (identical on all ranks).  `compute` provides coefficients/apply/dense_grad/adam_dense."""
+    every step (identical on all ranks).  `compute` provides coefficients/apply/dense_grad/adam_dense.
+    Buffers are allocated once per call; per step there is one compute call, one collective, one compute call."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     N = stream.shape[0]
-    Bg = batch_local * world
-    losses = []
-    for lo in range(0, N, Bg):
-        hi = min(N, lo + Bg)
-        nglob = hi - lo                                   # divisor of the mean (structure.py:849, short last batch)
-        mylo, myhi = shard_bounds(lo, hi, batch_local, rank)
-        local = stream[mylo:myhi]
-        if mode == "allgather":
-            mine = torch.zeros((2, batch_local), dtype=torch.float32, device=stream.device)
+    B = batch_local
+    Bg = B * world
+    nsteps = (N + Bg - 1) // Bg
+    dev = stream.device
+    if nsteps == 0:
+        return torch.empty(0, dtype=torch.float32, device=dev)
+    nglob_all = torch.tensor([min(N, lo + Bg) - lo for lo in range(0, N, Bg)], dtype=torch.float32, device=dev)
+    if mode == "allgather":
+        mine = torch.zeros((2, B), dtype=torch.float32, device=dev)
+        gathered = torch.empty((nsteps, world * 2 * B), dtype=torch.float32, device=dev)   # every step's exchange
+        g_all = torch.empty(Bg, dtype=torch.float32, device=dev)
+        for k, lo in enumerate(range(0, N, Bg)):
+            hi = min(N, lo + Bg)
+            nglob = hi - lo                               # divisor of the mean (structure.py:849, short last batch)
+            mylo, myhi = shard_bounds(lo, hi, B, rank)
+            if myhi - mylo < B:
+                mine.zero_()                              # padded slots must carry g = 0, term = 0
             if myhi > mylo:
-                mine[:, : myhi - mylo] = compute.coefficients(local, nglob)
-            flat = torch.empty(world * 2 * batch_local, dtype=torch.float32, device=stream.device)
-            dist.all_gather_into_tensor(flat, mine.reshape(-1), group=group)   # 1-D in, 1-D out: every backend
-            gathered = flat.view(world, 2, batch_local)
-            # rank-major order == global sample order; padded slots lie beyond nglob and are dropped
-            g_all = gathered[:, 0, :].reshape(-1)[:nglob]
-            t_all = gathered[:, 1, :].reshape(-1)[:nglob]
-            compute.apply(stream[lo:hi], g_all)
-            losses.append(t_all.sum() / nglob)
-        elif mode == "allreduce":
-            grad, terms = compute.dense_grad(local, nglob)
-            tsum = terms.sum().reshape(1) if myhi > mylo else torch.zeros(1, dtype=torch.float32, device=stream.device)
+                compute.coefficients(stream[mylo:myhi], nglob, out=mine)
+            dist.all_gather_into_tensor(gathered[k], mine.view(-1), group=group)   # 1-D in, 1-D out: every backend
+            # rank-major order == global sample order (contiguous shards of B); slots beyond nglob are padding
+            g_all.view(world, B).copy_(gathered[k].view(world, 2, B)[:, 0, :])
+            compute.apply(stream[lo:hi], g_all[:nglob])
+        terms = gathered.view(nsteps, world, 2, B)[:, :, 1, :].reshape(nsteps, Bg)
+        return terms.sum(dim=1) / nglob_all
+    if mode == "allreduce":
+        tsum = torch.zeros(nsteps, dtype=torch.float32, device=dev)
+        for k, lo in enumerate(range(0, N, Bg)):
+            hi = min(N, lo + Bg)
+            mylo, myhi = shard_bounds(lo, hi, B, rank)
+            grad, terms = compute.dense_grad(stream[mylo:myhi], hi - lo)
+            if myhi > mylo:
+                tsum[k] = terms.sum()
             dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(tsum, op=dist.ReduceOp.SUM, group=group)
             compute.adam_dense(grad)
-            losses.append(tsum[0] / nglob)
-        else:
-            raise ValueError(f"unknown data-parallel mode {mode!r}")
-    return torch.stack(losses) if losses else torch.empty(0, dtype=torch.float32, device=stream.device)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM, group=group)   # one reduction of all the step losses
+        return tsum / nglob_all
+    raise ValueError(f"unknown data-parallel mode {mode!r}")
 
 
 def broadcast_state(binding, src=0, group=None):

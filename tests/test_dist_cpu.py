@@ -56,9 +56,12 @@ class OracleCompute:
         for nm, gr in (("U", dU), ("V", dV)):
             self.orc.adam(self.st[nm], self.st["m" + nm], self.st["v" + nm], gr, self.step, lr=self.lr, wd=self.wd)
 
-    def coefficients(self, rec_local, divisor):
+    def coefficients(self, rec_local, divisor, out=None):
         g, term = self._g(rec_local, divisor)
-        return torch.from_numpy(np.stack([g, term]))
+        res = torch.from_numpy(np.stack([g, term]))
+        if out is not None:
+            out[:, : res.shape[1]] = res
+        return res
 
     def apply(self, rec_global, g_global):
         self._adam(*self._scatter(rec_global, g_global.numpy()))
