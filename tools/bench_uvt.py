@@ -1,0 +1,31 @@
+"""Diagnostic: time the dense UV^T metric pass (mfcd_uvt_stats) and price it against its roofline."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "matrix-factorization-with-comparison-data_amd")]
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+import torch
+from mfcd import metrics
+dev = torch.device("cuda:0")
+for name, n, m, d in [("C1", 256, 256, 8), ("C2", 4096, 4096, 64), ("C3", 16384, 16384, 128), ("C5", 100000, 20000, 256)]:
+    U = torch.randn(n, d, device=dev) / d ** 0.5
+    V = torch.randn(m, d, device=dev) / d ** 0.5
+    X = torch.randn(n, m, device=dev) * 0.5
+    metrics.uvt_stats(U, V, X, 1.0); torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        metrics.uvt_stats(U, V, X, 1.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    flops = 2.0 * n * m * d
+    bytes_ = 4.0 * n * m * 2 + 4.0 * (n + m) * d      # X is read twice (row-mean pre-pass + epilogue)
+    # torch reference of the reference's own op sequence for the same quantity (GEMM + centring + norms)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        M = U @ V.t(); M -= M.mean(0, keepdim=True); e = torch.norm(M - X) / torch.norm(X)
+    torch.cuda.synchronize()
+    dt_t = (time.perf_counter() - t1) / reps
+    print(f"{name}: n={n} m={m} d={d}  uvt_stats {dt*1e6:9.1f} us  = {flops/dt/1e12:6.2f} TFLOP/s ({flops/dt/157.3e12*100:5.1f}% of 157.3 TF fp32 MFMA)"
+          f"  X traffic {bytes_/dt/1e9:7.1f} GB/s ({bytes_/dt/8e12*100:4.1f}% of 8 TB/s) | torch-op sequence on the same GPU {dt_t*1e6:9.1f} us", flush=True)
+    del U, V, X
+    torch.cuda.empty_cache()
