@@ -89,14 +89,14 @@ ResidentPlan plan_resident(int n, int m, int d, int num_cus)
     return pl;
 }
 
-int launch_resident_steps(const ResidentPlan &pl, float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
                           const mfcd_sample *samples, int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev,
                           const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status,
                           unsigned long long *dbg, int K, hipStream_t st)
 {
     ResidentArgs a;
     a.dbg = dbg;
-    a.U = U; a.V = V; a.mU = mU; a.vU = vU; a.mV = mV; a.vV = vV;
+    a.cold = (const ResidentCold *)cold_dev;
     a.samples = samples; a.sc = sc_dev; a.mailbox = mailbox; a.loss_terms = loss_terms; a.status = status;
     a.N = N; a.B = B; a.n = n; a.m = m; a.K = K; a.NW = pl.NW; a.ac = ac;
     const char *la = getenv("MFCD_RESIDENT_LOOKAHEAD");  // tuning/test override: 0 disables look-ahead publishing

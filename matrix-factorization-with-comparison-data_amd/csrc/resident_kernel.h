@@ -34,8 +34,17 @@ __device__ __forceinline__ void store_granule(u64 *p, unsigned tag, float v)
 #define DBG_ADD(slot, val) ((void)0)
 #endif
 
-struct ResidentArgs {
+// Pointers needed only when the slice is loaded at kernel start and stored at kernel end.  They live in device
+// memory (workspace) and are (re)read with scalar loads at those two points, so they do not occupy SGPRs during
+// the step loop (with them passed by value the kernel needed > 102 SGPRs and spilled scalars into VGPR lanes on
+// every step).
+struct ResidentCold {
     float *U, *V, *mU, *vU, *mV, *vV;
+    unsigned long long pad[2];
+};
+
+struct ResidentArgs {
+    const ResidentCold *cold;
     const mfcd_sample *samples;
     const StepScalars *sc;   // [K]
     u64 *mailbox;            // [N][3][D] granules, zero-filled before the launch
@@ -93,13 +102,16 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 
     // ---- load my slice of the state into registers ----
     float p[Q], m1[Q], m2[Q], gr[Q];
+    {
+        const ResidentCold c = *a.cold;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int64_t e = ebase + q * 64 + lane;
-        p[q] = m1[q] = m2[q] = 0.0f;
-        if (e < T) {
-            if (e < TU) { p[q] = a.U[e]; m1[q] = a.mU[e]; m2[q] = a.vU[e]; }
-            else { p[q] = a.V[e - TU]; m1[q] = a.mV[e - TU]; m2[q] = a.vV[e - TU]; }
+        for (int q = 0; q < Q; ++q) {
+            const int64_t e = ebase + q * 64 + lane;
+            p[q] = m1[q] = m2[q] = 0.0f;
+            if (e < T) {
+                if (e < TU) { p[q] = c.U[e]; m1[q] = c.mU[e]; m2[q] = c.vU[e]; }
+                else { p[q] = c.V[e - TU]; m1[q] = c.mV[e - TU]; m2[q] = c.vV[e - TU]; }
+            }
         }
     }
 #ifdef MFCD_STAMPS
@@ -438,13 +450,16 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
     if (lane == 0 && a.dbg)
         for (int x = 0; x < 8; ++x) a.dbg[(int64_t)gw * 8 + x] = dbg_acc[x];
 #endif
-    // ---- write my slice back ----
+    // ---- write my slice back (the table pointers are re-read: they were not kept live across the loop) ----
+    const ResidentCold *cp = a.cold;
+    asm volatile("" : "+s"(cp));   // opaque to the optimiser: forces fresh scalar loads instead of 12 live SGPRs
+    const ResidentCold c = *cp;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int64_t e = ebase + q * 64 + lane;
         if (e < T) {
-            if (e < TU) { a.U[e] = p[q]; a.mU[e] = m1[q]; a.vU[e] = m2[q]; }
-            else { a.V[e - TU] = p[q]; a.mV[e - TU] = m1[q]; a.vV[e - TU] = m2[q]; }
+            if (e < TU) { c.U[e] = p[q]; c.mU[e] = m1[q]; c.vU[e] = m2[q]; }
+            else { c.V[e - TU] = p[q]; c.mV[e - TU] = m1[q]; c.vV[e - TU] = m2[q]; }
         }
     }
 }

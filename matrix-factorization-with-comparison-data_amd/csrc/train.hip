@@ -377,8 +377,10 @@ int device_cus()
 }
 
 struct ResidentLayout {
-    size_t dbg_off, sc_off, terms_off, mailbox_off, mailbox_bytes, total;
+    size_t dbg_off, cold_off, sc_off, terms_off, mailbox_off, mailbox_bytes, total;
 };
+
+constexpr size_t kColdBytes = 64;   // ResidentCold: six table pointers + padding, directly in front of the scalar table
 
 constexpr size_t kDbgBytes = 16 * 256 * 8 * 8;  // [<=4096 waves][8] u64 of the diagnostic build (tools/)
 
@@ -389,8 +391,9 @@ ResidentLayout resident_layout(int64_t N, int B, int d)
     size_t off = kStatusBytes;
     L.dbg_off = off;
     off += kDbgBytes;
-    L.sc_off = off;
-    off += align256(sizeof(StepScalars) * (size_t)(K > 0 ? K : 1));
+    L.cold_off = off;
+    L.sc_off = off + kColdBytes;
+    off += align256(kColdBytes + sizeof(StepScalars) * (size_t)(K > 0 ? K : 1));
     L.terms_off = off;
     off += align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
     L.mailbox_off = off;
@@ -421,7 +424,7 @@ bool resident_applies(int64_t N, int B, int n, int m, int d, mfcd_detail::Reside
 // pinned staging buffer for the per-step scalar table (grow-only, guarded by an event)
 struct Stage {
     std::mutex mu;
-    StepScalars *host = nullptr;
+    void *host = nullptr;
     size_t cap = 0;
     hipEvent_t ev = nullptr;
 };
@@ -490,14 +493,17 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
             std::lock_guard<std::mutex> lock(g_stage.mu);
             if (!g_stage.ev) MFCD_HIP_TRY(hipEventCreateWithFlags(&g_stage.ev, hipEventDisableTiming));
             else MFCD_HIP_TRY(hipEventSynchronize(g_stage.ev));  // previous upload has left the buffer
-            if (g_stage.cap < (size_t)nsteps) {
+            const size_t need = kColdBytes + sizeof(StepScalars) * (size_t)nsteps;
+            if (g_stage.cap < need) {
                 if (g_stage.host) (void)hipHostFree(g_stage.host);
-                g_stage.cap = (size_t)nsteps * 2;
-                MFCD_HIP_TRY(hipHostMalloc((void **)&g_stage.host, sizeof(StepScalars) * g_stage.cap, 0));
+                g_stage.cap = need * 2;
+                MFCD_HIP_TRY(hipHostMalloc((void **)&g_stage.host, g_stage.cap, 0));
             }
-            for (int64_t k = 0; k < nsteps; ++k) g_stage.host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
-            MFCD_HIP_TRY(hipMemcpyAsync(sc_dev, g_stage.host, sizeof(StepScalars) * (size_t)nsteps,
-                                        hipMemcpyHostToDevice, st));
+            void **cold = (void **)g_stage.host;   // {U, V, mU, vU, mV, vV, 0, 0}
+            cold[0] = U; cold[1] = V; cold[2] = mU; cold[3] = vU; cold[4] = mV; cold[5] = vV; cold[6] = cold[7] = nullptr;
+            StepScalars *sc_host = (StepScalars *)((char *)g_stage.host + kColdBytes);
+            for (int64_t k = 0; k < nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
+            MFCD_HIP_TRY(hipMemcpyAsync(base + L.cold_off, g_stage.host, need, hipMemcpyHostToDevice, st));
             MFCD_HIP_TRY(hipEventRecord(g_stage.ev, st));
         }
         MFCD_HIP_TRY(hipMemsetAsync(mailbox, 0, L.mailbox_bytes, st));
@@ -507,7 +513,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
             MFCD_HIP_TRY(hipEventCreate(&e1));
             MFCD_HIP_TRY(hipEventRecord(e0, st));
         }
-        if (int rc = mfcd_detail::launch_resident_steps(rp, (float *)U, (float *)V, mU, vU, mV, vV, samples, N, B, n, m, d, sc_dev,
+        if (int rc = mfcd_detail::launch_resident_steps(rp, base + L.cold_off, samples, N, B, n, m, d, sc_dev,
                                                        adam_static(beta1, beta2, eps, weight_decay), mailbox, terms_r,
                                                        status, (unsigned long long *)(base + L.dbg_off), (int)nsteps,
                                                        st))

@@ -87,7 +87,8 @@ extern int g_resident_math;
 
 ResidentPlan plan_resident(int n, int m, int d, int num_cus);
 
-int launch_resident_steps(const ResidentPlan &pl, float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+// cold_dev: device copy of {U, V, mU, vU, mV, vV, pad[2]} (64 bytes), see ResidentCold in resident_kernel.h
+int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
                           const mfcd_sample *samples, int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev,
                           const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status,
                           unsigned long long *dbg, int K, hipStream_t st);
