@@ -102,6 +102,9 @@ int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
     const char *la = getenv("MFCD_RESIDENT_LOOKAHEAD");  // tuning/test override: 0 disables look-ahead publishing
     a.lookahead = la ? atoi(la) : 4;
     if (N + 64 * 16 >= ((int64_t)1 << 31)) a.lookahead = 0;   // the look-ahead form indexes samples with 32 bits
+    // tiny tables: a batch touches so large a share of the rows that nearly every row recurs inside the window
+    // and each publish takes the deferred (slow) path; publishing right before use is faster there
+    if (!la && (int64_t)(n + m) < (int64_t)96 * B) a.lookahead = 0;
     a.fast_math = g_resident_math;
     const char *lp = getenv("MFCD_RESIDENT_LDS_PAD");   // experiment knob (bytes)
     a.lds_pad = lp ? atoi(lp) : 0;
