@@ -247,6 +247,7 @@ def _run():
     consumed = runner.run(args.steps, record=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    runner.engine.check_status()   # a resident launch that gave up on a bounded wait would invalidate the number
 
     from mfcd import _lib
     plan_resident = (cfg["d"] & (cfg["d"] - 1)) == 0 and 2 <= cfg["d"] <= 256 and (cfg["n"] + cfg["m"]) * cfg["d"] <= 2097152

@@ -105,7 +105,8 @@ int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
     // tiny tables: a batch touches so large a share of the rows that nearly every row recurs inside the window
     // and each publish takes the deferred (slow) path; publishing right before use is faster there
     if (!la && (int64_t)(n + m) < (int64_t)96 * B) a.lookahead = 0;
-    a.fast_math = g_resident_math;
+    const char *fm = getenv("MFCD_RESIDENT_MATH");   // experiment knob: "ieee" / "fast" overrides mfcd_set_resident_math
+    a.fast_math = fm ? (fm[0] == 'f') : g_resident_math;
     const char *lp = getenv("MFCD_RESIDENT_LDS_PAD");   // experiment knob (bytes)
     a.lds_pad = lp ? atoi(lp) : 0;
     ResidentLauncher fn = launcher_for(d);

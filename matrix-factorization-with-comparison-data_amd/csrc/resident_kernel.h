@@ -252,21 +252,27 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         constexpr int W = LOOK;
         const int N32 = (int)a.N;                                  // host guarantees N + 64*(W+2) < 2^31
         const bool ownsU = Rlo < a.n, ownsV = Rhi > a.n;
-        const int ulo = Rlo, ucnt = (Rhi < a.n ? Rhi : a.n) - Rlo;                       // my user rows
-        const int vlo = (Rlo > a.n ? Rlo : a.n) - a.n, vcnt = Rhi - a.n - vlo;           // my item rows (item ids)
-        auto load_rec = [&](int step) {                            // this lane's record of batch `step`
-            mfcd_sample s;
-            s.u = s.i = s.j = -0x40000000;
-            s.z = 0.0f;
+        // my user rows [ulo, ulo+ucnt) and item rows [vlo, vlo+vcnt) (item ids); a count of 0 makes the unsigned
+        // range test below fail for every id, so the scan needs no branch on what kind of rows I own
+        const int ulo = Rlo, ucnt = ownsU ? (Rhi < a.n ? Rhi : a.n) - Rlo : 0;
+        const int vlo = (Rlo > a.n ? Rlo : a.n) - a.n, vcnt = ownsV ? Rhi - a.n - vlo : 0;
+        // this lane's record of batch `step`: branch-free (clamped address, then inert ids for lanes past the batch
+        // or past the stream), 32-bit byte offset from a scalar base
+        const char *const sbase = (const char *)a.samples;
+        auto load_rec = [&](int step) {
             const int pos = step * a.B + lane;
-            if (lane < a.B && pos < N32) s = a.samples[pos];
+            const bool valid = lane < a.B && pos < N32;
+            const unsigned off = (unsigned)(valid ? pos : 0) * 16u;
+            mfcd_sample s = *(const mfcd_sample *)(sbase + off);
+            s.u = valid ? s.u : -0x40000000;
+            s.i = valid ? s.i : -0x40000000;
+            s.j = valid ? s.j : -0x40000000;
             return s;
         };
         auto any_mask = [&](const mfcd_sample &s) {                // inert lanes hold -2^30: never in range
-            bool h = false;
-            if (ownsU) h = (unsigned)(s.u - ulo) < (unsigned)ucnt;
-            if (ownsV) h = h || (unsigned)(s.i - vlo) < (unsigned)vcnt || (unsigned)(s.j - vlo) < (unsigned)vcnt;
-            return (u64)__ballot(h);
+            const unsigned du_ = (unsigned)(s.u - ulo), di_ = (unsigned)(s.i - vlo), dj_ = (unsigned)(s.j - vlo);
+            const unsigned dv_ = di_ < dj_ ? di_ : dj_;
+            return (u64)__ballot((du_ < (unsigned)ucnt) | (dv_ < (unsigned)vcnt));
         };
         auto role_masks = [&](const mfcd_sample &s) {
             Masks M;
