@@ -83,6 +83,9 @@ size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d);
  *   2 resident        one persistent launch per call, p/m/v held in registers, rows exchanged through
  *                     tagged 8-byte granules; needs d a power of two <= 256 and 12*(n+m)*d bytes of
  *                     state to fit the register files; MFCD_EINVAL from mfcd_train_steps otherwise
+ *   3 local           tiny problems ((n+m)*d <= 16384, B <= 4096, any d): one persistent launch of ONE
+ *                     workgroup, parameters in LDS, moments in registers, three barriers per step;
+ *                     MFCD_EINVAL otherwise.  "auto" picks local, then resident, then streaming.
  * Both forms compute the same step (same summation order per row); results agree to fp32 rounding.
  */
 int mfcd_set_train_path(int mode);

@@ -360,7 +360,7 @@ namespace {
 
 constexpr size_t kStatusBytes = 256;  // workspace[0..3] = int32 status word of the last resident launch
 
-int g_train_path = 0;  // 0 auto, 1 streaming, 2 resident (mfcd_set_train_path)
+int g_train_path = 0;  // 0 auto, 1 streaming, 2 resident, 3 local (mfcd_set_train_path)
 
 int device_cus()
 {
@@ -413,7 +413,7 @@ constexpr size_t kMaxMailboxBytes = (size_t)24 << 30;  // beyond this the stream
 
 bool resident_applies(int64_t N, int B, int n, int m, int d, mfcd_detail::ResidentPlan *out)
 {
-    if (g_train_path == 1 || N <= 0) return false;
+    if (g_train_path == 1 || g_train_path == 3 || N <= 0) return false;
     const mfcd_detail::ResidentPlan pl = mfcd_detail::plan_resident(n, m, d, device_cus());
     if (!pl.ok) return false;
     if (resident_layout(N, B, d).mailbox_bytes > kMaxMailboxBytes) return false;
@@ -434,7 +434,7 @@ Stage g_stage;
 
 extern "C" int mfcd_set_train_path(int mode)
 {
-    if (mode < 0 || mode > 2) return MFCD_EINVAL;
+    if (mode < 0 || mode > 3) return MFCD_EINVAL;
     g_train_path = mode;
     return 0;
 }
@@ -453,6 +453,10 @@ extern "C" size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int
     if (g_train_path != 1 && mfcd_detail::plan_resident(n, m, d, 256).ok) {
         const ResidentLayout L = resident_layout(N, B, d);
         if (L.mailbox_bytes <= kMaxMailboxBytes && L.total > need) need = L.total;
+    }
+    if (mfcd_detail::local_applies(N > 0 ? N : 1, B, n, m, d)) {
+        const ResidentLayout L = resident_layout(N, B, 0);   // the local form uses the same layout without a mailbox
+        if (L.total > need) need = L.total;
     }
     return need;
 }
@@ -477,8 +481,59 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     int *status = (int *)workspace;
     MFCD_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
 
+    constexpr bool kF32 = sizeof(TP) == 4;   // the resident / local forms hold fp32 state; bf16 factors stream
+    // ---- local form: tiny problems, one workgroup with the parameters in LDS (local.hip) ----
+    const bool local = kF32 && (g_train_path == 0 || g_train_path == 3) && mfcd_detail::local_applies(N, B, n, m, d);
+    if (g_train_path == 3 && !local) return MFCD_EINVAL;
+    if constexpr (kF32) if (local) {
+        if (nsteps > 0x7fffffff) return MFCD_EINVAL;
+        const ResidentLayout L = resident_layout(N, B, 0);   // status | dbg | cold | scalars | terms (no mailbox)
+        char *base = (char *)workspace;
+        StepScalars *sc_dev = (StepScalars *)(base + L.sc_off);
+        float *terms_l = (float *)(base + L.terms_off);
+        {
+            std::lock_guard<std::mutex> lock(g_stage.mu);
+            if (!g_stage.ev) MFCD_HIP_TRY(hipEventCreateWithFlags(&g_stage.ev, hipEventDisableTiming));
+            else MFCD_HIP_TRY(hipEventSynchronize(g_stage.ev));
+            const size_t need = sizeof(StepScalars) * (size_t)nsteps;
+            if (g_stage.cap < need) {
+                if (g_stage.host) (void)hipHostFree(g_stage.host);
+                g_stage.cap = need * 2;
+                MFCD_HIP_TRY(hipHostMalloc((void **)&g_stage.host, g_stage.cap, 0));
+            }
+            StepScalars *sc_host = (StepScalars *)g_stage.host;
+            for (int64_t k = 0; k < nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
+            MFCD_HIP_TRY(hipMemcpyAsync(sc_dev, g_stage.host, need, hipMemcpyHostToDevice, st));
+            MFCD_HIP_TRY(hipEventRecord(g_stage.ev, st));
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timing_us) {
+            MFCD_HIP_TRY(hipEventCreate(&e0));
+            MFCD_HIP_TRY(hipEventCreate(&e1));
+            MFCD_HIP_TRY(hipEventRecord(e0, st));
+        }
+        if (int rc = mfcd_detail::launch_local_steps((float *)U, (float *)V, mU, vU, mV, vV, samples, N, B, n, m, d,
+                                                    sc_dev, adam_static(beta1, beta2, eps, weight_decay), terms_l,
+                                                    (int)nsteps, st))
+            return rc;
+        if (timing_us) MFCD_HIP_TRY(hipEventRecord(e1, st));
+        if (loss_per_step) {
+            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms_l, samples, N, B,
+                               loss_per_step);
+            MFCD_HIP_TRY(hipGetLastError());
+        }
+        if (timing_us) {
+            MFCD_HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            MFCD_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            timing_us[0] = timing_us[1] = timing_us[2] = ms * 1e3f / (float)nsteps;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        return 0;
+    }
+
     mfcd_detail::ResidentPlan rp;
-    constexpr bool kF32 = sizeof(TP) == 4;   // the resident form holds fp32 state; bf16 factors use the streaming form
     const bool resident = kF32 && resident_applies(N, B, n, m, d, &rp);
     if (g_train_path == 2 && !resident) return MFCD_EINVAL;
     if constexpr (kF32) if (resident) {

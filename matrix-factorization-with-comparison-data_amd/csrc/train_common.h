@@ -78,6 +78,13 @@ __device__ __forceinline__ void adam_update_t(float &p, float &m1, float &m2, fl
 
 namespace mfcd_detail {
 
+// ---- local form (local.hip): one workgroup, parameters in LDS ----
+constexpr int64_t kLocalMaxElems = 16384;   // (n+m)*d: 64 KiB of parameters + 64 KiB of gradient accumulator in LDS
+bool local_applies(int64_t N, int B, int n, int m, int d);
+int launch_local_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *samples,
+                       int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev, const AdamStatic &ac,
+                       float *loss_terms, int K, hipStream_t st);
+
 struct ResidentPlan {
     bool ok;
     int Q, NW, blocks;

@@ -122,11 +122,11 @@ class Workspace:
 
 _ws = Workspace()
 
-TRAIN_PATHS = {"auto": 0, "streaming": 1, "resident": 2}
+TRAIN_PATHS = {"auto": 0, "streaming": 1, "resident": 2, "local": 3}
 
 
 def set_train_path(mode):
-    """Select the form of the fused step: "auto" (default), "streaming" or "resident" (include/mfcd.h)."""
+    """Select the form of the fused step: "auto" (default), "streaming", "resident" or "local" (include/mfcd.h)."""
     _lib.check(_lib.load().mfcd_set_train_path(TRAIN_PATHS[mode]))
 
 

@@ -32,7 +32,12 @@ def resident_applies(n, m, d):
     return 2 <= d <= 256 and (d & (d - 1)) == 0 and (n + m) * d <= 256 * 8 * 64 * 16
 
 
-@pytest.fixture(params=["streaming", "resident", "resident-ieee"])
+def local_applies(n, m, d, B=64):
+    """Mirror of local_applies (csrc/local.hip): the whole problem fits one workgroup's LDS."""
+    return (n + m) * d <= 16384 and 1 <= B <= 4096
+
+
+@pytest.fixture(params=["streaming", "resident", "resident-ieee", "local"])
 def path(request, dev):
     """Run a training test once per form of the fused step (include/mfcd.h: mfcd_set_train_path), the resident form
     in both arithmetic flavours (mfcd_set_resident_math: fast is the default)."""
@@ -84,6 +89,8 @@ def test_kat_steps_match_reference(dev, path, name):
     g = load_golden(name)
     if path == "resident" and not resident_applies(g["U0"].shape[0], g["V0"].shape[0], g["U0"].shape[1]):
         pytest.skip("resident form needs d to be a power of two")
+    if path == "local" and not local_applies(g["U0"].shape[0], g["V0"].shape[0], g["U0"].shape[1]):
+        pytest.skip("local form needs (n+m)*d <= 16384")
     lr, wd = float(g["lr"]), float(g["wd"])
     model, opt = _model_from(g["U0"], g["V0"], dev, lr, wd)
     bind = engine.AdamBinding(model, opt)
@@ -204,6 +211,8 @@ def test_train_epoch_matches_oracle(dev, orc, path, n, m, d, N, B, soft):
     from oracle import oracle as O
     if path == "resident" and not resident_applies(n, m, d):
         pytest.skip("resident form does not apply to this shape")
+    if path == "local" and not local_applies(n, m, d, B):
+        pytest.skip("local form does not apply to this shape")
     U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=n + d + N, soft=soft)
     lr, wd = 1e-3, 1e-5
     model, opt = _model_from(U0, V0, dev, lr, wd)
@@ -230,6 +239,12 @@ def test_train_epoch_matches_oracle(dev, orc, path, n, m, d, N, B, soft):
 
 
 def test_properties_at_c2_size(dev, path):
+    if path == "local":
+        pytest.skip("C2 does not fit one workgroup")
+    _properties_at_c2_size(dev)
+
+
+def _properties_at_c2_size(dev):
     """Size-independent properties at BASELINE C2: run-to-run bit reproducibility, call-splitting
     invariance (k steps in one call == the same steps over two calls), lr=0 & wd=0 leaves U,V untouched."""
     from mfcd import engine
@@ -259,6 +274,8 @@ def test_properties_at_c2_size(dev, path):
 
 
 def test_untouched_rows_move_by_weight_decay_only(dev, orc, path):
+    if path == "local":
+        pytest.skip("shape does not fit one workgroup")
     """Dense Adam is not optional (SURVEY §7): rows outside the batch still move through wd*p."""
     from mfcd import engine
     n = m = 512
@@ -332,19 +349,20 @@ def test_uvt_stats_match_oracle(dev, orc, n, m, d):
 
 def test_forms_agree_and_resident_rejects_unsupported_shapes(dev):
     from mfcd import _lib, engine
-    n, m, d, N, B = 512, 384, 32, 64 * 40 + 5, 64
+    n, m, d, N, B = 256, 192, 32, 64 * 40 + 5, 64
     U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=11, soft=True)
     st = _records(u, i, j, z, n, m, dev)
     outs = {}
     try:
-        for mode in ("streaming", "resident"):
+        for mode in ("streaming", "resident", "local"):
             engine.set_train_path(mode)
             model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
             loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B)
             engine.check_status()
             outs[mode] = (model.U.data.cpu().numpy(), model.V.data.cpu().numpy(), loss.cpu().numpy())
-        for a, b in zip(outs["streaming"], outs["resident"]):
-            np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)
+        for other in ("resident", "local"):
+            for a, b in zip(outs["streaming"], outs[other]):
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)
         engine.set_train_path("resident")
         U0, V0, u, i, j, z = _synthetic(40, 40, 5, 64, seed=2)
         model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)

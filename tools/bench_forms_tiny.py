@@ -1,0 +1,27 @@
+"""Diagnostic: the three forms of the fused step on tiny problems (C1 and the notebooks' default)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "matrix-factorization-with-comparison-data_amd")]
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+import numpy as np, torch
+import structure as S
+from mfcd import engine
+dev = torch.device("cuda:0")
+for name, n, m, d in (("C1", 256, 256, 8), ("notebook", 1000, 1000, 2), ("n=m=1000 d=8", 1000, 1000, 8)):
+    B, steps = 64, 2000
+    rng = np.random.default_rng(0); N = B * steps
+    rows = np.stack([rng.integers(0, n, N), rng.integers(0, m, N), rng.integers(0, m, N), rng.integers(0, 2, N)], 1).astype(np.float64)
+    rows[:, 2] = (rows[:, 1] + 1 + rng.integers(0, m - 1, N)) % m
+    for form in ("streaming", "resident", "local", "auto"):
+        engine.set_train_path(form)
+        model = S.MatrixFactorization(n, m, d).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        bind = engine.AdamBinding(model, opt)
+        st = engine.SampleStore(rows, n, m, dev)
+        try:
+            engine.train_steps(bind, st.dev, B); torch.cuda.synchronize()
+            t0 = time.perf_counter(); engine.train_steps(bind, st.dev, B); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            print(f"{name:14s} {form:9s}: {dt/steps*1e6:7.2f} us/step  ({B*steps/dt/1e6:6.2f} M updates/s)", flush=True)
+        except Exception as e:
+            print(f"{name:14s} {form:9s}: n/a ({e})", flush=True)
+engine.set_train_path("auto")
