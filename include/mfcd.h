@@ -85,7 +85,8 @@ size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d);
  *                     state to fit the register files; MFCD_EINVAL from mfcd_train_steps otherwise
  *   3 local           tiny problems ((n+m)*d <= 16384, B <= 4096, any d): one persistent launch of ONE
  *                     workgroup, parameters in LDS, moments in registers, three barriers per step;
- *                     MFCD_EINVAL otherwise.  "auto" picks local, then resident, then streaming.
+ *                     MFCD_EINVAL otherwise.  Measured no faster than the resident form (one CU's ALU and
+ *                     the serial per-row accumulation bound it), so "auto" does not select it.
  * Both forms compute the same step (same summation order per row); results agree to fp32 rounding.
  */
 int mfcd_set_train_path(int mode);

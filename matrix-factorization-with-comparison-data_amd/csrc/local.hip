@@ -9,7 +9,8 @@
 //            backward coefficient g_t -> LDS; the sigmoid output goes to the loss buffer.
 //   phase B  row gradients into an LDS accumulator: global row r belongs to wave r % 16, every wave walks the
 //            batch in order and handles its rows -> batch-order summation per row, no atomics, deterministic.
-//   phase C  dense Adam: thread t owns elements t, t+1024, ...; p in LDS, m/v in registers (IEEE flavour).
+//   phase C  dense Adam: thread t owns elements t, t+1024, ...; p in LDS, m/v in registers (flavour as
+//            mfcd_set_resident_math selects).
 // Same arithmetic and per-row summation order as the other two forms (structure.py:847-851 per step).
 #include "common.h"
 #include "train_common.h"
@@ -26,7 +27,7 @@ struct LocalArgs {
     AdamStatic ac;
 };
 
-template <int QL>
+template <int QL, bool FAST>
 __global__ __launch_bounds__(1024) void local_train_kernel(LocalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -49,11 +50,33 @@ __global__ __launch_bounds__(1024) void local_train_kernel(LocalArgs a)
     }
     __syncthreads();
 
+    // lane t of EVERY wave holds record t of the current batch's first 64 samples; the next batch is fetched
+    // while the current one is processed, so no phase waits on global memory for its records
+    auto load_chunk0 = [&](int step) {
+        mfcd_sample s;
+        s.u = s.i = s.j = 0;
+        s.z = 0.0f;
+        const int64_t pos = (int64_t)step * a.B + lane;
+        if (step < a.K && lane < a.B && pos < a.N) s = a.samples[pos];
+        return s;
+    };
+    auto lane_sample = [&](const mfcd_sample &s, int tl) {
+        mfcd_sample r;
+        r.u = __builtin_amdgcn_readlane(s.u, tl);
+        r.i = __builtin_amdgcn_readlane(s.i, tl);
+        r.j = __builtin_amdgcn_readlane(s.j, tl);
+        r.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.z), tl));
+        return r;
+    };
+    mfcd_sample rec = load_chunk0(0);
+    StepScalars sc = a.sc[0];
+
     for (int k = 0; k < a.K; ++k) {
         const int64_t pos0 = (int64_t)k * a.B;
         const int Bk = (int)((a.N - pos0) < a.B ? (a.N - pos0) : a.B);
         const float inv_batch = 1.0f / (float)Bk;
-        const StepScalars sc = a.sc[k];
+        const mfcd_sample rec_next = load_chunk0(k + 1);
+        const StepScalars sc_next = a.sc[k + 1 < a.K ? k + 1 : k];
 
         // ---- phase A: coefficients; clear the gradient accumulator ----
 #pragma unroll
@@ -62,7 +85,7 @@ __global__ __launch_bounds__(1024) void local_train_kernel(LocalArgs a)
             if (e < T) gacc[e] = 0.0f;
         }
         for (int t = wave; t < Bk; t += 16) {
-            const mfcd_sample s = a.samples[pos0 + t];
+            const mfcd_sample s = t < MFCD_WAVE ? lane_sample(rec, t) : a.samples[pos0 + t];
             const float *ur = pL + s.u * d, *vi = pL + TU + s.i * d, *vj = pL + TU + s.j * d;
             float acc = 0.0f;
             for (int c = lane; c < d; c += MFCD_WAVE) acc += ur[c] * (vi[c] - vj[c]);
@@ -81,7 +104,8 @@ __global__ __launch_bounds__(1024) void local_train_kernel(LocalArgs a)
             s.u = s.i = s.j = 0;
             s.z = 0.0f;
             const bool valid = t < Bk;
-            if (valid) s = a.samples[pos0 + t];
+            if (base == 0) s = rec;
+            else if (valid) s = a.samples[pos0 + t];
             const unsigned long long mu = __ballot(valid && (s.u & 15) == wave);
             const unsigned long long mi = __ballot(valid && ((s.i + a.n) & 15) == wave);
             const unsigned long long mj = __ballot(valid && ((s.j + a.n) & 15) == wave);
@@ -115,11 +139,13 @@ __global__ __launch_bounds__(1024) void local_train_kernel(LocalArgs a)
             const int e = tid + 1024 * q;
             if (e < T) {
                 float pe = pL[e];
-                adam_update(pe, m1[q], m2[q], gacc[e], a.ac, sc);
+                adam_update_t<FAST>(pe, m1[q], m2[q], gacc[e], a.ac, sc);
                 pL[e] = pe;
             }
         }
         __syncthreads();
+        rec = rec_next;
+        sc = sc_next;
     }
 
 #pragma unroll
@@ -135,9 +161,16 @@ __global__ __launch_bounds__(1024) void local_train_kernel(LocalArgs a)
 template <int QL>
 int launch_local(const LocalArgs &a, size_t lds_bytes, hipStream_t st)
 {
-    MFCD_HIP_TRY(hipFuncSetAttribute((const void *)local_train_kernel<QL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes));
-    hipLaunchKernelGGL((local_train_kernel<QL>), dim3(1), dim3(1024), lds_bytes, st, a);
+    // one CU does all the Adam arithmetic here, so the flavour matters even more than in the resident form
+    if (mfcd_detail::g_resident_math) {
+        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)local_train_kernel<QL, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((local_train_kernel<QL, true>), dim3(1), dim3(1024), lds_bytes, st, a);
+    } else {
+        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)local_train_kernel<QL, false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((local_train_kernel<QL, false>), dim3(1), dim3(1024), lds_bytes, st, a);
+    }
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }
