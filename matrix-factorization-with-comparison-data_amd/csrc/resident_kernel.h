@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                 while (mask) {
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    if (!process_hit(lane_sample(rk, tl), M0, tl, pos0 + tl, (unsigned)k + 1u, inv_batch)) return;
+                    // the abort decision is wave-uniform; saying so keeps the step loop free of exec-mask bookkeeping
+                    const bool ok = process_hit(lane_sample(rk, tl), M0, tl, pos0 + tl, (unsigned)k + 1u, inv_batch);
+                    if (__builtin_amdgcn_readfirstlane((int)!ok)) return;
                 }
             }
             [[maybe_unused]] const u64 t_adam0 = STAMP();
@@ -442,7 +444,8 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     hs.i = __shfl(s.i, tl, MFCD_WAVE);
                     hs.j = __shfl(s.j, tl, MFCD_WAVE);
                     hs.z = __shfl(s.z, tl, MFCD_WAVE);
-                    if (!process_hit(hs, M, tl, pos0 + base + tl, (unsigned)k + 1u, inv_batch)) return;
+                    const bool ok = process_hit(hs, M, tl, pos0 + base + tl, (unsigned)k + 1u, inv_batch);
+                    if (__builtin_amdgcn_readfirstlane((int)!ok)) return;
                 }
             }
 #pragma unroll
