@@ -371,13 +371,14 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         publish_phase(-1, true);
 
         StepScalars sc_cur = a.sc[0];
+        const StepScalars *sc_ptr = a.sc + 1;      // running pointer: the table holds K+1 entries (host pads one)
         for (int k = 0; k < a.K; ++k) {
             // slide the window: anyw[0] becomes batch k; scan batch k+W (record prefetched during the last step)
 #pragma unroll
             for (int b2 = 0; b2 < W; ++b2) anyw[b2] = anyw[b2 + 1];
             anyw[W] = any_mask(rec_new);
             rec_new = load_rec(k + W + 1);
-            const StepScalars sc_next = a.sc[k + 1 < a.K ? k + 1 : k];
+            const StepScalars sc_next = *sc_ptr++;
 
 #pragma unroll
             for (int q = 0; q < Q; ++q) gr[q] = 0.0f;

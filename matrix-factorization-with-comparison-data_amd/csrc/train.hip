@@ -393,7 +393,7 @@ ResidentLayout resident_layout(int64_t N, int B, int d)
     off += kDbgBytes;
     L.cold_off = off;
     L.sc_off = off + kColdBytes;
-    off += align256(kColdBytes + sizeof(StepScalars) * (size_t)(K > 0 ? K : 1));
+    off += align256(kColdBytes + sizeof(StepScalars) * (size_t)(K + 1));   // one pad entry: the kernel reads step k+1
     L.terms_off = off;
     off += align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
     L.mailbox_off = off;
@@ -550,7 +550,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
             std::lock_guard<std::mutex> lock(g_stage.mu);
             if (!g_stage.ev) MFCD_HIP_TRY(hipEventCreateWithFlags(&g_stage.ev, hipEventDisableTiming));
             else MFCD_HIP_TRY(hipEventSynchronize(g_stage.ev));  // previous upload has left the buffer
-            const size_t need = kColdBytes + sizeof(StepScalars) * (size_t)nsteps;
+            const size_t need = kColdBytes + sizeof(StepScalars) * (size_t)(nsteps + 1);
             if (g_stage.cap < need) {
                 if (g_stage.host) (void)hipHostFree(g_stage.host);
                 g_stage.cap = need * 2;
@@ -559,7 +559,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
             void **cold = (void **)g_stage.host;   // {U, V, mU, vU, mV, vV, 0, 0}
             cold[0] = U; cold[1] = V; cold[2] = mU; cold[3] = vU; cold[4] = mV; cold[5] = vV; cold[6] = cold[7] = nullptr;
             StepScalars *sc_host = (StepScalars *)((char *)g_stage.host + kColdBytes);
-            for (int64_t k = 0; k < nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
+            for (int64_t k = 0; k <= nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
             MFCD_HIP_TRY(hipMemcpyAsync(base + L.cold_off, g_stage.host, need, hipMemcpyHostToDevice, st));
             MFCD_HIP_TRY(hipEventRecord(g_stage.ev, st));
         }
