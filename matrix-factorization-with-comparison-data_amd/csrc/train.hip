@@ -483,9 +483,9 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
 
     constexpr bool kF32 = sizeof(TP) == 4;   // the resident / local forms hold fp32 state; bf16 factors stream
     // ---- local form: tiny problems, one workgroup with the parameters in LDS (local.hip) ----
-    // measured (profiles/r01_tiny_problem_forms.txt): it only ties the resident form at <= 4096 elements and loses above,
-    // so it is used when asked for (mode 3) and is not part of "auto"
-    const bool local = kF32 && g_train_path == 3 && mfcd_detail::local_applies(N, B, n, m, d);
+    // measured (profiles/r01_tiny_problem_forms.txt): 1.2-5.7x faster than the resident form wherever it applies
+    // ((n+m)*d <= 8192), so "auto" takes it first
+    const bool local = kF32 && (g_train_path == 3 || g_train_path == 0) && mfcd_detail::local_applies(N, B, n, m, d);
     if (g_train_path == 3 && !local) return MFCD_EINVAL;
     if constexpr (kF32) if (local) {
         if (nsteps > 0x7fffffff) return MFCD_EINVAL;

@@ -68,6 +68,45 @@ __device__ __forceinline__ void adam_update_fast(float &p, float &m1, float &m2,
     p = p + div_newton(num, den, __builtin_amdgcn_rcpf(den));
 }
 
+// The fast flavour on TWO elements at once with gfx950's packed fp32 instructions (v_pk_fma_f32, v_pk_mul_f32,
+// v_pk_add_f32: one issue slot for both halves).  Every packed operation rounds each half exactly like its scalar
+// counterpart and the operation sequence is the one above, so the results are bit-identical to two calls of
+// adam_update_fast; only the square roots and reciprocals stay scalar.  20 issue slots per pair instead of 36.
+typedef float mfcd_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mfcd_f2 f2_splat(float x) { return (mfcd_f2){x, x}; }
+__device__ __forceinline__ mfcd_f2 f2_fma(mfcd_f2 a, mfcd_f2 b, mfcd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ mfcd_f2 div_newton2(mfcd_f2 a, mfcd_f2 b, mfcd_f2 r)
+{
+#pragma clang fp contract(off)
+    const mfcd_f2 q0 = a * r;
+    const mfcd_f2 e = f2_fma(-b, q0, a);
+    return f2_fma(e, r, q0);
+}
+
+__device__ __forceinline__ void adam_update_fast2(float &pa, float &pb, float &m1a, float &m1b, float &m2a, float &m2b,
+                                                  float ga, float gb, const AdamStatic &ac, const StepScalars &sc)
+{
+#pragma clang fp contract(off)
+    mfcd_f2 p = {pa, pb}, m1 = {m1a, m1b}, m2 = {m2a, m2b};
+    const mfcd_f2 g = f2_fma(f2_splat(ac.wd), p, (mfcd_f2){ga, gb});
+    m1 = f2_fma(f2_splat(ac.w1), g - m1, m1);
+    const mfcd_f2 v_scaled = m2 * f2_splat(ac.b2);
+    const mfcd_f2 gg = (f2_splat(ac.w2) * g) * g;
+    m2 = v_scaled + gg;
+    const mfcd_f2 sq = {__builtin_amdgcn_sqrtf(m2.x), __builtin_amdgcn_sqrtf(m2.y)};
+    const mfcd_f2 den = div_newton2(sq, f2_splat(sc.bc2_sqrt), f2_splat(sc.inv_bc2_sqrt)) + f2_splat(ac.eps);
+    const mfcd_f2 num = f2_splat(sc.neg_step_size) * m1;
+    const mfcd_f2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    p = p + div_newton2(num, den, rc);
+    pa = p.x; pb = p.y; m1a = m1.x; m1b = m1.y; m2a = m2.x; m2b = m2.y;
+}
+
+// Q elements of one thread: pairs through the packed form when FAST && PACKED, scalar otherwise.
+template <bool FAST, int Q, bool PACKED>
+__device__ __forceinline__ void adam_update_q(float (&p)[Q], float (&m1)[Q], float (&m2)[Q], const float (&g)[Q],
+                                              const AdamStatic &ac, const StepScalars &sc);
+
 template <bool FAST>
 __device__ __forceinline__ void adam_update_t(float &p, float &m1, float &m2, float gsparse, const AdamStatic &ac,
                                               const StepScalars &sc)
@@ -76,10 +115,24 @@ __device__ __forceinline__ void adam_update_t(float &p, float &m1, float &m2, fl
     else adam_update(p, m1, m2, gsparse, ac, sc);
 }
 
+template <bool FAST, int Q, bool PACKED>
+__device__ __forceinline__ void adam_update_q(float (&p)[Q], float (&m1)[Q], float (&m2)[Q], const float (&g)[Q],
+                                              const AdamStatic &ac, const StepScalars &sc)
+{
+    if constexpr (FAST && PACKED && Q % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; q += 2)
+            adam_update_fast2(p[q], p[q + 1], m1[q], m1[q + 1], m2[q], m2[q + 1], g[q], g[q + 1], ac, sc);
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) adam_update_t<FAST>(p[q], m1[q], m2[q], g[q], ac, sc);
+    }
+}
+
 namespace mfcd_detail {
 
 // ---- local form (local.hip): one workgroup, parameters in LDS ----
-constexpr int64_t kLocalMaxElems = 16384;   // (n+m)*d: 64 KiB of parameters + 64 KiB of gradient accumulator in LDS
+constexpr int64_t kLocalMaxElems = 8192;   // (n+m)*d: above this one CU's vector ALU is slower than the multi-CU resident form
 bool local_applies(int64_t N, int B, int n, int m, int d);
 int launch_local_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *samples,
                        int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev, const AdamStatic &ac,

@@ -19,6 +19,10 @@
 // Roofline: MFMA-bound for d >= 64 (2*n*m*d flop vs 4*n*m bytes of X), HBM-bound (X read) below.
 #include "common.h"
 
+#ifndef MFCD_UVT_EXP
+#define MFCD_UVT_EXP 0   // diagnostic builds only (tools/): 1 no X loads, 2 no f64 epilogue, 3 no MFMA
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -231,6 +235,189 @@ __global__ __launch_bounds__(256) void uvt_main_kernel(const float *__restrict__
     if (lane == 0) part_err[(size_t)split * ((n + 31) / 32) + rt] = err2;
 }
 
+// Tiled form of the main kernel for D in {32, 64, 128, 256}: a workgroup of NW waves owns NW*32 rows of U (each
+// wave keeps its 32-row A fragment in registers for the whole sweep, as above) and the TC-column stages of V are
+// staged through LDS once per WORKGROUP (double-buffered, one barrier per stage, coalesced 16-byte global loads
+// issued a stage ahead) instead of once per wave from L2 — at D = 256 the per-wave V fetch (32 KiB per 32x32
+// tile) was what bounded the kernel.  LDS rows are padded by 4 floats so the per-lane 16-byte fragment reads
+// (lane = column, stride = one row) spread over the banks.  With NW = 8 two waves share a SIMD, so one wave's
+// f64 epilogue overlaps the other's MFMA chain.
+// Work mapping is XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs by the hardware; when there are
+// >= 8 column splits, every row block of split s runs on XCD s % 8, whose L2 then serves that split's V rows.
+template <int D, int NW, int TC>
+__global__ __launch_bounds__(NW * 64) void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
+                                                            const float *__restrict__ X, const float *__restrict__ rm,
+                                                            const float *__restrict__ cm, const float *__restrict__ xm,
+                                                            int n, int m, float s, int cols_per_split, int splits,
+                                                            int row_blocks, double *__restrict__ part_rows,
+                                                            double *__restrict__ part_err)
+{
+    constexpr int LD = D + 4, NT = NW * 64, NLD = TC * D / 4 / NT;   // padded LDS row; float4 loads per thread per stage
+    static_assert(TC * D / 4 % NT == 0 && TC % 32 == 0, "stage must split evenly over the workgroup");
+    extern __shared__ __attribute__((aligned(16))) float vt[];   // [2][TC][LD]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar, so that row bases below stay in SGPRs
+    int split, rb;
+    if (splits >= 8) {
+        const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+        split = (w / row_blocks) * 8 + xcd;
+        rb = w % row_blocks;
+    } else {
+        split = blockIdx.x / row_blocks;
+        rb = blockIdx.x % row_blocks;
+    }
+    if (split >= splits) return;   // whole workgroup
+    const int rt = rb * NW + wave, row0 = rt * 32;
+    const bool active = row0 < n;  // waves past the last row still help with the V stages and the barriers
+    const int c_begin = split * cols_per_split;
+    const int c_end = min(m, c_begin + cols_per_split);
+
+    float a[D / 2];
+    float rmr[16], xmr[16];
+    bool rok[16];
+    double sac[16], saa[16];
+    {
+        const float *urow = U + (int64_t)min(row0 + l31, n - 1) * D + half * (D / 2);
+#pragma unroll
+        for (int q = 0; q < D / 8; ++q) {
+            const float4 t = *reinterpret_cast<const float4 *>(urow + 4 * q);
+            a[4 * q + 0] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + tile_row(r, half);
+        rok[r] = row < n;
+        const int rc = min(row, n - 1);
+        rmr[r] = rm[rc];
+        xmr[r] = xm[rc];
+        sac[r] = 0.0;
+        saa[r] = 0.0;
+    }
+    double err2 = 0.0;
+
+    // this thread's share of a V stage: NLD 16-byte pieces, piece idx = tid + i*NT -> (row idx / (D/4), float4 idx % (D/4))
+    float4 stg[NLD];
+#define MFCD_LOAD_STAGE(C0)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
+        const int idx = tid + i * NT, r = idx / (D / 4), k4 = idx % (D / 4);                                 \
+        stg[i] = *reinterpret_cast<const float4 *>(V + (int64_t)min((C0) + r, m - 1) * D + 4 * k4);         \
+    }
+#define MFCD_STORE_STAGE(BUF)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
+        const int idx = tid + i * NT, r = idx / (D / 4), k4 = idx % (D / 4);                                 \
+        *reinterpret_cast<float4 *>(vt + (size_t)(BUF) * TC * LD + r * LD + 4 * k4) = stg[i];                \
+    }
+    MFCD_LOAD_STAGE(c_begin)
+    MFCD_STORE_STAGE(0)
+    __syncthreads();
+
+    int buf = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += TC) {
+        const bool has_next = c0 + TC < c_end;
+        if (has_next) { MFCD_LOAD_STAGE(c0 + TC) }
+        if (active) {
+#pragma unroll 1
+            for (int j = 0; j < TC / 32; ++j) {
+                const int cb = c0 + 32 * j;
+                if (cb >= c_end) break;
+                const int col = cb + l31;
+                const bool cok = col < c_end;
+                const int cc = min(col, m - 1);
+                // X tile: scalar row base (rows past n are masked below, so any in-range row will do: clamp so that
+                // the +4 of the upper lane half stays inside) + one 32-bit lane offset
+                float x[16];
+                const unsigned xoff = (unsigned)(half * 4) * (unsigned)m + (unsigned)cc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float *xr = X + (int64_t)min(row0 + tile_row(r, 0), n - 5) * m;
+#if MFCD_UVT_EXP == 1
+                    x[r] = (float)xoff;
+#else
+                    x[r] = xr[xoff];
+#endif
+                }
+                const float cmc = cm[cc];
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                const float *brow = vt + (size_t)buf * TC * LD + (32 * j + l31) * LD + half * (D / 2);
+                // B fragments from LDS in batches of QB 16-byte reads, one batch ahead of the MFMAs that consume them
+                // (the scheduling barrier keeps the compiler from hoisting every read to the top: 64+ registers)
+                constexpr int QB = 4, NB = D / 8 / QB;
+                float4 t[2][QB];
+#pragma unroll
+                for (int q = 0; q < QB; ++q) t[0][q] = *reinterpret_cast<const float4 *>(brow + 4 * q);
+#pragma unroll
+                for (int bi = 0; bi < NB; ++bi) {
+                    if (bi + 1 < NB) {
+#pragma unroll
+                        for (int q = 0; q < QB; ++q)
+                            t[(bi + 1) & 1][q] = *reinterpret_cast<const float4 *>(brow + 4 * ((bi + 1) * QB + q));
+                    }
+#pragma unroll
+                    for (int q = 0; q < QB; ++q) {
+                        const float4 tq = t[bi & 1][q];
+                        const int k0 = 4 * (bi * QB + q);
+#if MFCD_UVT_EXP == 3
+                        acc[0] += a[k0] * tq.x + a[k0 + 1] * tq.y + a[k0 + 2] * tq.z + a[k0 + 3] * tq.w;
+                        continue;
+#endif
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k0 + 0], tq.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k0 + 1], tq.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k0 + 2], tq.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k0 + 3], tq.w, acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {   // branch-free: out-of-range rows / columns contribute exact zeros
+                    const bool ok = rok[r] && cok;
+                    const float g = acc[r];
+                    const float av = ok ? g - rmr[r] : 0.0f;             // structure.py:985
+                    const float cv = x[r] - xmr[r];                      // structure.py:987
+                    const float e = ok ? (g - cmc) - s * x[r] : 0.0f;    // structure.py:943, 949
+#if MFCD_UVT_EXP == 2
+                    err2 += (double)(av + cv + e);
+                    continue;
+#endif
+                    sac[r] += (double)av * (double)cv;
+                    saa[r] += (double)av * (double)av;
+                    err2 += (double)e * (double)e;
+                }
+            }
+        }
+        if (has_next) { MFCD_STORE_STAGE(buf ^ 1) }
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef MFCD_LOAD_STAGE
+#undef MFCD_STORE_STAGE
+    if (!active) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            sac[r] += __shfl_xor(sac[r], off, MFCD_WAVE);
+            saa[r] += __shfl_xor(saa[r], off, MFCD_WAVE);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off, MFCD_WAVE);
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + tile_row(r, half);
+            if (row < n) {
+                double *o = part_rows + ((size_t)split * n + row) * 2;
+                o[0] = sac[r];
+                o[1] = saa[r];
+            }
+        }
+    }
+    if (lane == 0) part_err[(size_t)split * ((n + 31) / 32) + rt] = err2;
+}
+
 // row_stats[r][8] and scal[4] from the partials (fixed order → deterministic)
 __global__ __launch_bounds__(256) void uvt_final_kernel(const double *__restrict__ part_rows,
                                                         const double *__restrict__ part_err,
@@ -296,18 +483,52 @@ struct UvtWs {
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
+struct TiledCfg {
+    int NW, TC;   // waves per workgroup (32 rows each), columns per LDS stage; NW == 0: no tiled form for this d
+};
+
+TiledCfg tiled_cfg(int d)
+{
+    switch (d) {
+    case 256: return {4, 32};    // A fragment = 128 registers: one wave per SIMD
+    case 128: return {8, 32};
+    case 64: return {8, 64};
+    case 32: return {8, 128};
+    default: return {0, 0};
+    }
+}
+
 UvtWs plan_ws(char *base, int n, int m, int d)
 {
     UvtWs w;
     const int rtiles = (n + 31) / 32;
-    // enough (row tile, split) wave items to fill 256 CUs several times over, 32-column granularity
-    int splits = 1;
-    const int ctiles = (m + 31) / 32;
-    while (splits < ctiles && (int64_t)rtiles * splits < 4096) splits *= 2;
-    if (splits > ctiles) splits = ctiles;
-    if (splits > 64) splits = 64;
-    w.cols_per_split = ((ctiles + splits - 1) / splits) * 32;
-    w.splits = (m + w.cols_per_split - 1) / w.cols_per_split;
+    const TiledCfg tc = n >= 32 ? tiled_cfg(d) : TiledCfg{0, 0};
+    if (tc.NW) {
+        // tiled form: >= ~3 workgroups per CU in total, a split's V rows small enough for one XCD's L2 (4 MiB),
+        // >= 2 stages per split; 8 or more splits (a multiple of 8 where the column count allows) so that the
+        // XCD-aware mapping applies
+        const int row_blocks = (n + tc.NW * 32 - 1) / (tc.NW * 32);
+        const int stages = (m + tc.TC - 1) / tc.TC;
+        int64_t want = (768 + row_blocks - 1) / row_blocks;
+        const int64_t by_l2 = ((int64_t)m * d * 4 + (2 << 20) - 1) / (2 << 20);
+        if (by_l2 > want) want = by_l2;
+        int splits = want <= 1 ? 1 : (int)((want + 7) / 8 * 8);
+        const int max_splits = stages / 2 > 0 ? stages / 2 : 1;
+        if (splits > max_splits) splits = max_splits >= 8 ? max_splits / 8 * 8 : max_splits;
+        if (splits > 256) splits = 256;
+        const int per = (stages + splits - 1) / splits;
+        w.cols_per_split = per * tc.TC;
+        w.splits = (m + w.cols_per_split - 1) / w.cols_per_split;
+    } else {
+        // enough (row tile, split) wave items to fill 256 CUs several times over, 32-column granularity
+        int splits = 1;
+        const int ctiles = (m + 31) / 32;
+        while (splits < ctiles && (int64_t)rtiles * splits < 4096) splits *= 2;
+        if (splits > ctiles) splits = ctiles;
+        if (splits > 64) splits = 64;
+        w.cols_per_split = ((ctiles + splits - 1) / splits) * 32;
+        w.splits = (m + w.cols_per_split - 1) / w.cols_per_split;
+    }
     w.n_err = w.splits * rtiles;
     size_t off = 0;
     auto take = [&](size_t b) { char *p = base ? base + off : nullptr; off += al(b); return p; };
@@ -347,10 +568,26 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
     hipLaunchKernelGGL(x_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
     const dim3 grid(((n + 31) / 32 + 3) / 4, w.splits);
     const bool al16 = ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15u) == 0;
+    const TiledCfg tc = n >= 32 ? tiled_cfg(d) : TiledCfg{0, 0};
 #define MFCD_UVT(DD)                                                                                            \
     hipLaunchKernelGGL((uvt_main_kernel<DD>), grid, dim3(256), 0, st, U, V, X, w.rm, w.cm, w.xm, n, m, d, (float)s, \
                        w.cols_per_split, w.part_rows, w.part_err)
-    if (al16 && d == 8) MFCD_UVT(8);
+#define MFCD_UVT_TILED(DD, NW, TC)                                                                               \
+    do {                                                                                                         \
+        const int row_blocks = (n + NW * 32 - 1) / (NW * 32);                                                    \
+        const unsigned blocks = (unsigned)row_blocks * (w.splits >= 8 ? 8u * ((w.splits + 7) / 8) : (unsigned)w.splits); \
+        const size_t lds = sizeof(float) * 2 * TC * (DD + 4);                                                    \
+        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)uvt_tiled_kernel<DD, NW, TC>,                             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC>), dim3(blocks), dim3(NW * 64), lds, st, U, V, X, w.rm,   \
+                           w.cm, w.xm, n, m, (float)s, w.cols_per_split, w.splits, row_blocks, w.part_rows,      \
+                           w.part_err);                                                                          \
+    } while (0)
+    if (al16 && tc.NW && d == 256) MFCD_UVT_TILED(256, 4, 32);
+    else if (al16 && tc.NW && d == 128) MFCD_UVT_TILED(128, 8, 32);
+    else if (al16 && tc.NW && d == 64) MFCD_UVT_TILED(64, 8, 64);
+    else if (al16 && tc.NW && d == 32) MFCD_UVT_TILED(32, 8, 128);
+    else if (al16 && d == 8) MFCD_UVT(8);
     else if (al16 && d == 16) MFCD_UVT(16);
     else if (al16 && d == 32) MFCD_UVT(32);
     else if (al16 && d == 64) MFCD_UVT(64);
@@ -358,6 +595,7 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
     else if (al16 && d == 256) MFCD_UVT(256);
     else MFCD_UVT(0);
 #undef MFCD_UVT
+#undef MFCD_UVT_TILED
     hipLaunchKernelGGL(uvt_final_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, w.xm,
                        w.scc, w.sxx, n, w.splits, w.n_err, s, row_stats, scal);
     MFCD_HIP_TRY(hipGetLastError());

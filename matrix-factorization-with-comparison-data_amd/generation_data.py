@@ -20,15 +20,65 @@ def _accept(t, i, j, exclude, found):
     return i != j and t not in exclude and t not in found
 
 
-def choose_items_random(X, num_triplets, exclude):
-    """Uniform u, i, j (ref:16-26); one randint(n) and one randint(m, size 2) per attempt."""
-    n, m = X.shape
+def _choose_items_random_serial(n, m, num_triplets, exclude):
     found = set()
     while len(found) < num_triplets:
         u = int(torch.randint(0, n, (1,)))
         i, j = torch.randint(0, m, (2,)).tolist()
         if _accept((u, i, j), i, j, exclude, found):
             found.add((u, i, j))
+    return list(found)
+
+
+def choose_items_random(X, num_triplets, exclude):
+    """Uniform u, i, j (ref:16-26): per attempt one randint(n) and one randint(m, size 2), rejected when i == j,
+    excluded or already drawn.
+
+    Vectorised without changing a single draw: ATen's CPU randint takes one 32-bit Mersenne-Twister word w per
+    element and returns w % range, serially, so `randint(0, L, (3A,))` with L = lcm(n, m) yields words whose
+    residues mod n / mod m are exactly the A attempts' (u, i, j).  Attempts are drawn in blocks, filtered with
+    numpy, and the generator is then rewound and advanced by exactly the number of attempts the one-at-a-time
+    loop would have used, so everything drawn afterwards (labels, initial factors, shuffles) is unchanged.
+    The accepted triplets go into a Python set in attempt order: `list(set)` order is part of the contract
+    (the 80/10/10 split indexes into it, ref:705-718)."""
+    n, m = X.shape
+    exclude = exclude or set()
+    L = math.lcm(int(n), int(m))
+    if L >= 2 ** 32 or num_triplets <= 0:
+        return _choose_items_random_serial(n, m, num_triplets, exclude)
+    if num_triplets + len(exclude) > n * m * (m - 1):
+        raise ValueError(f"cannot draw {num_triplets} distinct triplets from a {n} x {m} matrix")
+    enc = lambda a: (a[:, 0] * m + a[:, 1]) * m + a[:, 2]                       # noqa: E731
+    barred = np.sort(enc(np.asarray(list(exclude), dtype=np.int64).reshape(-1, 3))) if exclude else None
+    state0 = torch.get_rng_state()
+    taken, taken_keys, attempts, need = [], np.empty(0, dtype=np.int64), 0, int(num_triplets)
+    while need > 0:
+        block = max(4096, need + need // 8 + 64)
+        w = torch.randint(0, L, (3 * block,)).numpy().reshape(block, 3)
+        cand = np.stack((w[:, 0] % n, w[:, 1] % m, w[:, 2] % m), axis=1)
+        key = enc(cand)
+        ok = cand[:, 1] != cand[:, 2]
+        if barred is not None:
+            ok &= ~np.isin(key, barred)
+        if taken_keys.size:
+            ok &= ~np.isin(key, taken_keys)
+        idx = np.flatnonzero(ok)
+        _, first = np.unique(key[idx], return_index=True)                      # first attempt of every new triplet
+        idx = idx[np.sort(first)]
+        if idx.size >= need:
+            idx = idx[:need]
+            attempts += int(idx[-1]) + 1
+        else:
+            attempts += block
+        taken.append(cand[idx])
+        taken_keys = np.concatenate((taken_keys, key[idx]))
+        need -= idx.size
+    torch.set_rng_state(state0)
+    torch.randint(0, L, (3 * attempts,))                                        # leave the generator where the loop would
+    rows = np.concatenate(taken)
+    found = set()
+    for t in zip(rows[:, 0].tolist(), rows[:, 1].tolist(), rows[:, 2].tolist()):
+        found.add(t)
     return list(found)
 
 
@@ -239,13 +289,32 @@ def choose_items_by_user_similarity(X, num_triplets, exclude=None, max_attempts=
 # ------------------------------------------------------------------------------------------------
 # ground-truth generators (ref:346-715)
 # ------------------------------------------------------------------------------------------------
+def _haar_columns(dim, k):
+    """First k columns of scipy.stats.ortho_group.rvs(dim) drawn from numpy's global RNG, without the O(dim^3) work.
+
+    ortho_group (scipy 1.15 _multivariate.py: rvs) draws z = normal(size=(dim, dim)), takes q, r = qr(z) and flips
+    the sign of column c of q by sign(r[c, c]).  Columns 0..k-1 of q and of r's diagonal only depend on columns
+    0..k-1 of z (Householder QR proceeds column by column), so the same dim*dim normals are drawn here in row
+    blocks — which leaves numpy's generator in exactly the state the full call would — and only the dim x k panel
+    is factorised.  Agrees with the full call to ~1e-16 (tests/test_host_logic.py)."""
+    k = min(k, dim)
+    panel = np.empty((dim, k))
+    block = max(1, min(dim, (1 << 22) // max(dim, 1)))      # ~32 MiB of normals at a time
+    for r0 in range(0, dim, block):
+        r1 = min(dim, r0 + block)
+        panel[r0:r1] = np.random.normal(size=(r1 - r0, dim))[:, :k]
+    q, r = np.linalg.qr(panel)
+    diag = np.diagonal(r)
+    return q * (diag / abs(diag))
+
+
 def generate_embeddings(n, m, d, device="cpu"):
     """"base" X (ref:346-370): Q_n diag(1/sqrt(d) on the first d) Q_m^T * sqrt(nm)/2 with Haar orthogonal
     Q_n, Q_m drawn (in this order) by scipy's ortho_group from numpy's global RNG.  Only the first d
-    columns of each matter, so the product is formed from the n x d and m x d slices."""
-    from scipy.stats import ortho_group
-    A = ortho_group.rvs(dim=n)[:, :d]
-    B = ortho_group.rvs(dim=m)[:, :d]
+    columns of each matter, so only those are formed (same RNG consumption, see _haar_columns)."""
+    k = min(d, n, m)                      # the reference's spectrum has min(d, n, m) non-zero entries, each 1/sqrt(d)
+    A = _haar_columns(n, k)
+    B = _haar_columns(m, k)
     X = (A / np.sqrt(d)) @ B.T * (np.sqrt(n * m) / 2)
     return torch.tensor(X, dtype=torch.float32, device=device)
 
@@ -263,9 +332,8 @@ def generate_embedding_factors(n, m, d, device="cpu", generator=None):
 
 def generate_low_rank_matrix(n, m, d, rank, device="cpu"):
     """Orthonormal n x d, m x d frames and a 0/1 spectrum with `rank` ones (ref:373-391)."""
-    from scipy.stats import ortho_group
-    A = torch.tensor(ortho_group.rvs(dim=n)[:, :d], dtype=torch.float32, device=device)
-    B = torch.tensor(ortho_group.rvs(dim=m)[:, :d], dtype=torch.float32, device=device)
+    A = torch.tensor(_haar_columns(n, d), dtype=torch.float32, device=device)
+    B = torch.tensor(_haar_columns(m, d), dtype=torch.float32, device=device)
     S = torch.zeros(d)
     S[:rank] = 1.0
     return A, B, S.to(device) if torch.device(device).type != "cpu" else S

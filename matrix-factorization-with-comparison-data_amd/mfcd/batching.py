@@ -20,6 +20,10 @@ def dataset_records(dataset):
 
     Fast path: the reference's BTLPreferenceDataset keeps a Python list of 4-tuples in `.data`
     (structure.py:491, 527-531).  Anything else is read item by item."""
+    fn = getattr(dataset, "_mfcd_records", None)   # this build's BTLPreferenceDataset: rows already an array
+    rows = fn() if callable(fn) else None
+    if rows is not None:
+        return np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 4)
     data = getattr(dataset, "data", None)
     if isinstance(data, np.ndarray) and data.ndim == 2 and data.shape[1] == 4:
         return np.ascontiguousarray(data, dtype=np.float64)

@@ -89,7 +89,9 @@ class SampleStore:
     @classmethod
     def from_loader(cls, loader, n, m, device):
         ds = loader.dataset
-        key = (id(getattr(ds, "data", ds)), len(ds), n, m, str(device))
+        fn = getattr(ds, "_mfcd_records", None)
+        rows = fn() if callable(fn) else None
+        key = (id(rows if rows is not None else getattr(ds, "data", ds)), len(ds), n, m, str(device))
         cached = getattr(ds, "_mfcd_store", None)
         if cached is not None and cached[0] == key:
             return cached[1]

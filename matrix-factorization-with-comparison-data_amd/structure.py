@@ -124,31 +124,70 @@ def compute_ground_truth_metrics(test_loader, X, device):
 class BTLPreferenceDataset(Dataset):
     """ref:465-531.  `.data` is a list of (u, i, j, label) tuples.  Labels are drawn with ONE
     vectorised torch.bernoulli call over all rows, which consumes the CPU generator exactly like the
-    reference's one-call-per-row loop (same serial kernel, same order)."""
+    reference's one-call-per-row loop (same serial kernel, same order).
+
+    The rows are kept as one float64 [N, 4] array (what the device path uploads); the Python list of
+    tuples behind `.data` is only built when somebody reads `.data`, and from then on that list is
+    the source of truth (callers may edit or replace it, as they can with the reference's)."""
 
     def __init__(self, triplets, X, scale=1.0, K=1, soft_label=False, train=False):
         self.X, self.scale, self.soft_label = X, scale, soft_label
-        self.data = self._generate_labels(triplets, K, train=train)
+        self._rows = self._label_rows(triplets, K, train)
+        self._data = None
+
+    def _label_rows(self, triplets, K, train):
+        idx = np.asarray(list(triplets) if not isinstance(triplets, (list, np.ndarray)) else triplets,
+                         dtype=np.int64).reshape(-1, 3)
+        if idx.shape[0] == 0:
+            return np.empty((0, 4), dtype=np.float64)
+        it = torch.from_numpy(idx)
+        Xc = self.X.detach()
+        dev_idx = it.to(Xc.device)
+        diff = (Xc[dev_idx[:, 0], dev_idx[:, 1]] - Xc[dev_idx[:, 0], dev_idx[:, 2]]).to("cpu")
+        score = torch.sigmoid(self.scale * diff)                          # ref:509 (fp32, CPU op as there)
+        draws = torch.bernoulli(score.repeat_interleave(K)).view(idx.shape[0], K)
+        if self.soft_label and train:                                   # ref:510-513
+            # torch.mean of K fp32 0/1 draws, then .item() -> Python float
+            rows = np.empty((idx.shape[0], 4), dtype=np.float64)
+            rows[:, :3] = idx
+            rows[:, 3] = draws.mean(dim=1).double().numpy()
+            return rows
+        rows = np.empty((idx.shape[0] * K, 4), dtype=np.float64)         # ref:516-518: K rows per triplet
+        rows[:, :3] = np.repeat(idx, K, axis=0)
+        rows[:, 3] = draws.reshape(-1).double().numpy()
+        return rows
 
     def _generate_labels(self, triplets, K, train=False):
-        trip = [tuple(int(v) for v in t) for t in triplets]
-        if not trip:
-            return []
-        idx = torch.tensor(trip, dtype=torch.int64)
-        Xc = self.X.detach().to("cpu")
-        score = torch.sigmoid(self.scale * (Xc[idx[:, 0], idx[:, 1]] - Xc[idx[:, 0], idx[:, 2]]))  # ref:509
-        draws = torch.bernoulli(score.repeat_interleave(K)).view(len(trip), K)
-        if self.soft_label and train:                                   # ref:510-513
-            lab = draws.mean(dim=1).tolist()
-            return [(u, i, j, l) for (u, i, j), l in zip(trip, lab)]
-        flat = draws.reshape(-1).tolist()                               # ref:516-518
-        return [trip[r // K] + (flat[r],) for r in range(len(flat))]
+        """ref:493-519 → list of (u, i, j, label)."""
+        return self._tuples(self._label_rows(triplets, K, train))
+
+    @staticmethod
+    def _tuples(rows):
+        ints = rows[:, :3].astype(np.int64)
+        return list(zip(ints[:, 0].tolist(), ints[:, 1].tolist(), ints[:, 2].tolist(), rows[:, 3].tolist()))
+
+    def _mfcd_records(self):
+        """float64 [N, 4] rows for the device path, or None once `.data` has been handed out."""
+        return self._rows
+
+    @property
+    def data(self):
+        if self._data is None:
+            self._data, self._rows = self._tuples(self._rows), None
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data, self._rows = value, None
 
     def __len__(self):
-        return len(self.data)
+        return self._rows.shape[0] if self._rows is not None else len(self._data)
 
     def __getitem__(self, idx):
-        return self.data[idx]
+        if self._rows is None:
+            return self._data[idx]
+        r = self._rows[idx]
+        return (int(r[0]), int(r[1]), int(r[2]), float(r[3]))
 
 
 _STRATEGIES = {

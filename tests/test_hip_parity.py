@@ -33,8 +33,16 @@ def resident_applies(n, m, d):
 
 
 def local_applies(n, m, d, B=64):
-    """Mirror of local_applies (csrc/local.hip): the whole problem fits one workgroup's LDS."""
-    return (n + m) * d <= 16384 and 1 <= B <= 4096
+    """Mirror of local_applies (csrc/local.hip): the whole problem fits one workgroup's LDS and vector ALU."""
+    pad = lambda v: (v + 3) & ~3  # noqa: E731
+    T = (n + m) * d
+    ql = -(-T // 1024)
+    ql = 1 if ql <= 1 else 2 if ql <= 2 else 4 if ql <= 4 else 8
+    lds = 4 * (2 * ql * 1024 + 3 * pad(n + m) + pad(B)) + 16 * B + 16
+    lps = 1
+    while lps < d and lps < 8:
+        lps *= 2
+    return T <= 8192 and 1 <= B <= 4096 and 3 * B <= 2 * (1024 // lps) and lds <= 160 * 1024
 
 
 @pytest.fixture(params=["streaming", "resident", "resident-ieee", "local"])
@@ -90,7 +98,7 @@ def test_kat_steps_match_reference(dev, path, name):
     if path == "resident" and not resident_applies(g["U0"].shape[0], g["V0"].shape[0], g["U0"].shape[1]):
         pytest.skip("resident form needs d to be a power of two")
     if path == "local" and not local_applies(g["U0"].shape[0], g["V0"].shape[0], g["U0"].shape[1]):
-        pytest.skip("local form needs (n+m)*d <= 16384")
+        pytest.skip("local form needs (n+m)*d <= 8192")
     lr, wd = float(g["lr"]), float(g["wd"])
     model, opt = _model_from(g["U0"], g["V0"], dev, lr, wd)
     bind = engine.AdamBinding(model, opt)
@@ -205,6 +213,11 @@ def _synthetic(n, m, d, N, seed, soft=False):
     (500, 400, 16, 2000, 200, False),     # B > 64
     (128, 96, 256, 130, 1, False),        # B = 1
     (2048, 1024, 32, 4096, 4096, False),  # one huge batch
+    (40, 30, 100, 900, 200, True),        # tiny tables, d > 64 and not a power of two, B > 64
+    (100, 60, 4, 4000, 2000, False),      # tiny tables, B > one workgroup's threads
+    (24, 16, 100, 900, 64, True),         # local form: 13 column chunks per lane group
+    (50, 40, 16, 800, 80, False),         # local form: both hit slots of a lane group on the same table
+    (300, 212, 16, 3000, 64, False),      # local form at its largest (8 elements per thread)
 ])
 def test_train_epoch_matches_oracle(dev, orc, path, n, m, d, N, B, soft):
     from mfcd import engine
@@ -349,7 +362,7 @@ def test_uvt_stats_match_oracle(dev, orc, n, m, d):
 
 def test_forms_agree_and_resident_rejects_unsupported_shapes(dev):
     from mfcd import _lib, engine
-    n, m, d, N, B = 256, 192, 32, 64 * 40 + 5, 64
+    n, m, d, N, B = 128, 96, 32, 64 * 40 + 5, 64
     U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=11, soft=True)
     st = _records(u, i, j, z, n, m, dev)
     outs = {}

@@ -192,3 +192,54 @@ def test_labels_follow_btl_statistics():
     assert len(soft) == 50 and all(r[3] in (0.0, 0.25, 0.5, 0.75, 1.0) for r in soft.data)
     hard = S.BTLPreferenceDataset([(0, 0, 1)] * 50, X, K=4, soft_label=True, train=False)
     assert len(hard) == 200 and all(r[3] in (0.0, 1.0) for r in hard.data)
+
+
+@pytest.mark.parametrize("dim,k", [(40, 3), (257, 8), (64, 64), (5, 9)])
+def test_haar_columns_equal_scipy_ortho_group(dim, k):
+    """The panel form of the "base" generator draws the same normals and yields the same leading columns as
+    scipy.stats.ortho_group.rvs (what generation_data.py:365-366 of the reference calls)."""
+    import generation_data as G
+    from scipy.stats import ortho_group
+    np.random.seed(dim + k)
+    want = ortho_group.rvs(dim=dim)[:, :k]
+    after_full = np.random.normal()
+    np.random.seed(dim + k)
+    got = G._haar_columns(dim, k)
+    assert np.random.normal() == after_full, "numpy RNG left in a different state"
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("n,m,k,n_excl", [(30, 30, 200, 0), (17, 23, 300, 50), (64, 8, 400, 100), (5, 4, 60, 0)])
+def test_vectorised_random_sampler_equals_one_at_a_time_loop(n, m, k, n_excl):
+    """Same triplets in the same list order and the same generator state as the reference's per-attempt loop
+    (generation_data.py:16-26), including rejections (i == j, excluded, duplicate)."""
+    import generation_data as G
+    X = torch.zeros(n, m)
+    torch.manual_seed(n * m + k)
+    excl = set(G._choose_items_random_serial(n, m, n_excl, set()))
+    torch.manual_seed(k)
+    want = G._choose_items_random_serial(n, m, k, excl)
+    state_want = torch.get_rng_state()
+    torch.manual_seed(k)
+    got = G.choose_items_random(X, k, excl)
+    assert got == want
+    assert torch.equal(torch.get_rng_state(), state_want)
+
+
+def test_dataset_rows_and_lazy_data_list():
+    import structure as S
+    from mfcd.batching import dataset_records
+    torch.manual_seed(3)
+    X = torch.randn(6, 5)
+    trip = [(0, 1, 2), (5, 4, 0), (3, 3, 1)]
+    ds = S.BTLPreferenceDataset(trip, X, K=2)
+    assert len(ds) == 6 and ds[1][:3] == (0, 1, 2) and isinstance(ds[1][3], float) and isinstance(ds[1][0], int)
+    rows = dataset_records(ds)
+    assert rows.shape == (6, 4) and rows.dtype == np.float64
+    data = ds.data                                   # materialises the reference's list of tuples
+    assert isinstance(data, list) and data[2][:3] == (5, 4, 0) and all(type(v) is int for v in data[2][:3])
+    np.testing.assert_array_equal(np.asarray(data), rows)
+    ds.data[0] = (1, 1, 1, 0.5)                      # callers may edit the list; the device path must see it
+    assert dataset_records(ds)[0].tolist() == [1.0, 1.0, 1.0, 0.5] and ds[0] == (1, 1, 1, 0.5)
+    ds.data = [(2, 2, 3, 1.0)]
+    assert len(ds) == 1 and dataset_records(ds).tolist() == [[2.0, 2.0, 3.0, 1.0]]

@@ -7,7 +7,8 @@ import numpy as np, torch
 import structure as S
 from mfcd import engine
 dev = torch.device("cuda:0")
-for name, n, m, d in (("C1", 256, 256, 8), ("notebook", 1000, 1000, 2), ("n=m=1000 d=8", 1000, 1000, 8)):
+for name, n, m, d in (("C1", 256, 256, 8), ("notebook", 1000, 1000, 2), ("n=m=100 d=4", 100, 100, 4),
+                      ("n=m=500 d=8", 500, 500, 8), ("n=m=1000 d=4", 1000, 1000, 4), ("n=m=1000 d=8", 1000, 1000, 8)):
     B, steps = 64, 2000
     rng = np.random.default_rng(0); N = B * steps
     rows = np.stack([rng.integers(0, n, N), rng.integers(0, m, N), rng.integers(0, m, N), rng.integers(0, 2, N)], 1).astype(np.float64)

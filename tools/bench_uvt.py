@@ -6,7 +6,10 @@ os.environ.setdefault("OMP_NUM_THREADS", "4")
 import torch
 from mfcd import metrics
 dev = torch.device("cuda:0")
+only = set(sys.argv[1:])
 for name, n, m, d in [("C1", 256, 256, 8), ("C2", 4096, 4096, 64), ("C3", 16384, 16384, 128), ("C5", 100000, 20000, 256)]:
+    if only and name not in only:
+        continue
     U = torch.randn(n, d, device=dev) / d ** 0.5
     V = torch.randn(m, d, device=dev) / d ** 0.5
     X = torch.randn(n, m, device=dev) * 0.5
@@ -20,11 +23,13 @@ for name, n, m, d in [("C1", 256, 256, 8), ("C2", 4096, 4096, 64), ("C3", 16384,
     flops = 2.0 * n * m * d
     bytes_ = 4.0 * n * m * 2 + 4.0 * (n + m) * d      # X is read twice (row-mean pre-pass + epilogue)
     # torch reference of the reference's own op sequence for the same quantity (GEMM + centring + norms)
-    t1 = time.perf_counter()
-    for _ in range(reps):
-        M = U @ V.t(); M -= M.mean(0, keepdim=True); e = torch.norm(M - X) / torch.norm(X)
-    torch.cuda.synchronize()
-    dt_t = (time.perf_counter() - t1) / reps
+    dt_t = float("nan")
+    if not os.environ.get("MFCD_SKIP_TORCH"):
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            M = U @ V.t(); M -= M.mean(0, keepdim=True); e = torch.norm(M - X) / torch.norm(X)
+        torch.cuda.synchronize()
+        dt_t = (time.perf_counter() - t1) / reps
     print(f"{name}: n={n} m={m} d={d}  uvt_stats {dt*1e6:9.1f} us  = {flops/dt/1e12:6.2f} TFLOP/s ({flops/dt/157.3e12*100:5.1f}% of 157.3 TF fp32 MFMA)"
           f"  X traffic {bytes_/dt/1e9:7.1f} GB/s ({bytes_/dt/8e12*100:4.1f}% of 8 TB/s) | torch-op sequence on the same GPU {dt_t*1e6:9.1f} us", flush=True)
     del U, V, X
