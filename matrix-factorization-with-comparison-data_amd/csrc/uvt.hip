@@ -269,6 +269,7 @@ __global__ __launch_bounds__(NW * 64) void uvt_tiled_kernel(const float *__restr
     if (split >= splits) return;   // whole workgroup
     const int rt = rb * NW + wave, row0 = rt * 32;
     const bool active = row0 < n;  // waves past the last row still help with the V stages and the barriers
+    const bool full_rows = row0 + 32 <= n;   // wave-uniform: every row of this wave's tile exists
     const int c_begin = split * cols_per_split;
     const int c_end = min(m, c_begin + cols_per_split);
 
@@ -328,14 +329,19 @@ __global__ __launch_bounds__(NW * 64) void uvt_tiled_kernel(const float *__restr
                 // the +4 of the upper lane half stays inside) + one 32-bit lane offset
                 float x[16];
                 const unsigned xoff = (unsigned)(half * 4) * (unsigned)m + (unsigned)cc;
+                if (full_rows) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float *xr = X + (int64_t)min(row0 + tile_row(r, 0), n - 5) * m;
+                    for (int r = 0; r < 16; ++r) {
+                        const float *xr = X + (int64_t)(row0 + tile_row(r, 0)) * m;
 #if MFCD_UVT_EXP == 1
-                    x[r] = (float)xoff;
+                        x[r] = (float)xoff;
 #else
-                    x[r] = xr[xoff];
+                        x[r] = xr[xoff];
 #endif
+                    }
+                } else {   // last row tile of a ragged n: per-lane clamped rows (rows past n are masked below)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[r] = X[(int64_t)min(row0 + tile_row(r, half), n - 1) * m + cc];
                 }
                 const float cmc = cm[cc];
                 f32x16 acc;

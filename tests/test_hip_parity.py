@@ -331,7 +331,7 @@ def test_empty_and_error_paths(dev):
 
 
 @pytest.mark.parametrize("n,m,d", [(4096, 4096, 64), (1000, 777, 8), (300, 5000, 128), (257, 95, 2), (96, 64, 256),
-                                   (130, 70, 24)])
+                                   (130, 70, 24), (301, 203, 64), (1003, 333, 256), (70, 517, 32), (33, 40, 128)])
 def test_uvt_stats_match_oracle(dev, orc, n, m, d):
     from mfcd import metrics
     rng = np.random.default_rng(n + m + d)
