@@ -27,22 +27,44 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kSlices = 128;  // row slices for the deterministic column-sum of U and V
+constexpr int kSlices = 256;  // row slices for the deterministic column-sum of U and V
 
-// partial[slice][k] = sum over rows of the slice of T[row][k]  (f64), grid = (kSlices, 2 tables)
+// partial[slice][k] = sum over rows of the slice of T[row][k]  (f64), grid = (kSlices, 2 tables).
+// The 256 threads form G = 256/d row groups (1 when d >= 256): thread -> (group g, column k); a group walks every
+// G-th row of the slice with four loads in flight, the groups are combined through LDS in fixed order.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ U, const float *__restrict__ V,
                                                              int n, int m, int d, double *__restrict__ part)
 {
+    __shared__ double red[256];
     const bool isV = blockIdx.y == 1;
     const float *T = isV ? V : U;
     const int rows = isV ? m : n;
     const int per = (rows + kSlices - 1) / kSlices;
     const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
     double *out = part + ((size_t)blockIdx.y * kSlices + blockIdx.x) * d;
-    for (int k = threadIdx.x; k < d; k += 256) {
-        double acc = 0.0;
-        for (int r = r0; r < r1; ++r) acc += (double)T[(int64_t)r * d + k];
-        out[k] = acc;
+    const int G = d >= 256 ? 1 : 256 / d;
+    for (int kb = 0; kb < d; kb += 256) {
+        const int g = d >= 256 ? 0 : (int)threadIdx.x / d;
+        const int k = d >= 256 ? kb + (int)threadIdx.x : (int)threadIdx.x % d;
+        const bool live = g < G && k < d;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (live) {
+            int r = r0 + g;
+            for (; r + 3 * G < r1; r += 4 * G) {
+                const float t0 = T[(int64_t)r * d + k], t1 = T[(int64_t)(r + G) * d + k];
+                const float t2 = T[(int64_t)(r + 2 * G) * d + k], t3 = T[(int64_t)(r + 3 * G) * d + k];
+                a0 += (double)t0; a1 += (double)t1; a2 += (double)t2; a3 += (double)t3;
+            }
+            for (; r < r1; r += G) a0 += (double)T[(int64_t)r * d + k];
+        }
+        red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (live && g == 0) {
+            double acc = 0.0;
+            for (int gg = 0; gg < G; ++gg) acc += red[gg * d + k - kb];
+            out[k] = acc;
+        }
+        __syncthreads();
     }
 }
 
@@ -79,7 +101,10 @@ __global__ __launch_bounds__(256) void centre_vectors_kernel(const float *__rest
     }
 }
 
-// One wave per row of X: xrow[r] = {mean (fp32), sum (x-mean)^2 (f64), sum x^2 (f64)}
+// One wave per row of X, ONE sweep: xm[r] = fp32 mean, sxx[r] = sum x^2, scc[r] = sum (x - xm)^2 formed in f64 as
+// sum x^2 - 2 xm sum x + m xm^2 with the fp32-rounded mean the reference centres with (structure.py:987).
+// XV: rows are 16-byte aligned (m % 4 == 0): 16-byte loads, four per lane in flight.
+template <bool XV>
 __global__ __launch_bounds__(256) void x_rows_kernel(const float *__restrict__ X, int n, int m, float *__restrict__ xm,
                                                      double *__restrict__ scc, double *__restrict__ sxx)
 {
@@ -88,28 +113,48 @@ __global__ __launch_bounds__(256) void x_rows_kernel(const float *__restrict__ X
     if (r >= n) return;
     const float *row = X + r * m;
     double s1 = 0.0, s2 = 0.0;
-    for (int c = lane; c < m; c += MFCD_WAVE) {
-        const double x = (double)row[c];
-        s1 += x;
-        s2 += x * x;
+    if constexpr (XV) {
+        const float4 *row4 = reinterpret_cast<const float4 *>(row);
+        const int n4 = m >> 2;
+        int c = lane;
+        for (; c + 192 < n4; c += 256) {
+            const float4 t0 = row4[c], t1 = row4[c + 64], t2 = row4[c + 128], t3 = row4[c + 192];
+            const float v[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w,
+                                 t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const double x = (double)v[q];
+                s1 += x;
+                s2 += x * x;
+            }
+        }
+        for (; c < n4; c += 64) {
+            const float4 t = row4[c];
+            const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double x = (double)v[q];
+                s1 += x;
+                s2 += x * x;
+            }
+        }
+    } else {
+        for (int c = lane; c < m; c += MFCD_WAVE) {
+            const double x = (double)row[c];
+            s1 += x;
+            s2 += x * x;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         s1 += __shfl_xor(s1, off, MFCD_WAVE);
         s2 += __shfl_xor(s2, off, MFCD_WAVE);
     }
-    // second sweep with the fp32 mean, as the reference centres in fp32 (structure.py:987)
-    const float mean = (float)(s1 / (double)m);
-    double cc = 0.0;
-    for (int c = lane; c < m; c += MFCD_WAVE) {
-        const double cx = (double)(row[c] - mean);
-        cc += cx * cx;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cc += __shfl_xor(cc, off, MFCD_WAVE);
     if (lane == 0) {
+        const float mean = (float)(s1 / (double)m);
+        const double mu = (double)mean;
         xm[r] = mean;
-        scc[r] = cc;
+        scc[r] = fmax(0.0, s2 - 2.0 * mu * s1 + (double)m * mu * mu);
         sxx[r] = s2;
     }
 }
@@ -235,30 +280,76 @@ __global__ __launch_bounds__(256) void uvt_main_kernel(const float *__restrict__
     if (lane == 0) part_err[(size_t)split * ((n + 31) / 32) + rt] = err2;
 }
 
-// Tiled form of the main kernel for D in {32, 64, 128, 256}: a workgroup of NW waves owns NW*32 rows of U (each
-// wave keeps its 32-row A fragment in registers for the whole sweep, as above) and the TC-column stages of V are
-// staged through LDS once per WORKGROUP (double-buffered, one barrier per stage, coalesced 16-byte global loads
-// issued a stage ahead) instead of once per wave from L2 — at D = 256 the per-wave V fetch (32 KiB per 32x32
-// tile) was what bounded the kernel.  LDS rows are padded by 4 floats so the per-lane 16-byte fragment reads
-// (lane = column, stride = one row) spread over the banks.  With NW = 8 two waves share a SIMD, so one wave's
-// f64 epilogue overlaps the other's MFMA chain.
-// Work mapping is XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs by the hardware; when there are
-// >= 8 column splits, every row block of split s runs on XCD s % 8, whose L2 then serves that split's V rows.
-template <int D, int NW, int TC>
-__global__ __launch_bounds__(NW * 64) void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
+// Tiled form of the main kernel for D in {32, 64, 128, 256}.
+//
+// A workgroup of NW waves owns NW*32 rows of U; the columns of its split arrive as TC-column stages of V in LDS,
+// once per WORKGROUP, written by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass),
+// double-buffered, one barrier per stage.  The LDS image of a stage is the plain [TC][D] array with the 16-byte
+// chunks of every row XOR-permuted (chunk p of row r holds logical chunk p ^ swz(r)); the permutation is applied
+// to the per-lane SOURCE address of the DMA and undone in the fragment read address, and makes the per-lane
+// 16-byte fragment reads (lane = column, stride = one row) conflict-free in every 16-lane group of ds_read_b128.
+//
+// Each wave computes the TRANSPOSED tile: V rows are the MFMA's A operand, the wave's 32 U rows (registers, for
+// the whole sweep) its B operand, so that in the accumulator layout a lane holds ONE row of U V^T and 16 of its
+// columns (4 runs of 4 consecutive columns).  Per-row sums are then per-lane scalars (no 16-wide f64 accumulator
+// arrays) and the matching X values are four 16-byte loads per lane.  Inside a tile the epilogue sums its 16
+// terms in fp32 (explicit fmaf), across tiles in f64.
+template <int D> struct StageSwz {
+    static constexpr int CPR = D / 4;                       // 16-byte chunks per row
+    static constexpr int RP = CPR >= 16 ? 1 : 16 / CPR;     // rows per 256-byte bank span
+    __device__ static __forceinline__ int of(int r) { return CPR >= 16 ? (r & 15) : ((r / RP) & (CPR - 1)); }
+};
+
+__device__ __forceinline__ void lds_dma16(const float *src, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr(const float *p)
+{
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+}
+__device__ __forceinline__ unsigned opaque(unsigned x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// 16-byte LDS read issued without the compiler's wait bookkeeping; pair with lds_wait4 before the first use.
+__device__ __forceinline__ void lds_read16_issue(f32x4 &dst, unsigned byte_addr)
+{
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(byte_addr) : "memory");
+}
+// wait until at most N LDS operations are outstanding; the operands tie the consumers to the wait
+template <int N>
+__device__ __forceinline__ void lds_wait4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const float *src, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+}
+
+template <int D, int NW, int TC, bool XV>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(D >= 256 ? 2 : 3)))
+void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
                                                             const float *__restrict__ X, const float *__restrict__ rm,
                                                             const float *__restrict__ cm, const float *__restrict__ xm,
                                                             int n, int m, float s, int cols_per_split, int splits,
                                                             int row_blocks, double *__restrict__ part_rows,
                                                             double *__restrict__ part_err)
 {
-    constexpr int LD = D + 4, NT = NW * 64, NLD = TC * D / 4 / NT;   // padded LDS row; float4 loads per thread per stage
-    static_assert(TC * D / 4 % NT == 0 && TC % 32 == 0, "stage must split evenly over the workgroup");
-    extern __shared__ __attribute__((aligned(16))) float vt[];   // [2][TC][LD]
+    using Sw = StageSwz<D>;
+    constexpr int CPR = Sw::CPR, PIECES = TC * D / 256, PPW = PIECES / NW, CMW = (TC + 63) / 64;
+    static_assert(PIECES % NW == 0 && TC % 32 == 0 && CMW <= NW, "stage must split evenly over the waves");
+    __shared__ __attribute__((aligned(16))) float vts[2][TC * D];     // [buffer][TC][D], chunks permuted
+    __shared__ __attribute__((aligned(16))) float cmss[2][CMW * 64];  // column means of U V^T for the stage's columns
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar, so that row bases below stay in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int split, rb;
-    if (splits >= 8) {
+    if (splits >= 8) {   // workgroup ids go round-robin to the 8 XCDs: keep a split's V rows in one XCD's L2
         const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
         split = (w / row_blocks) * 8 + xcd;
         rb = w % row_blocks;
@@ -268,197 +359,240 @@ __global__ __launch_bounds__(NW * 64) void uvt_tiled_kernel(const float *__restr
     }
     if (split >= splits) return;   // whole workgroup
     const int rt = rb * NW + wave, row0 = rt * 32;
-    const bool active = row0 < n;  // waves past the last row still help with the V stages and the barriers
-    const bool full_rows = row0 + 32 <= n;   // wave-uniform: every row of this wave's tile exists
+    const bool active = row0 < n;  // waves past the last row still issue their share of the stages
     const int c_begin = split * cols_per_split;
     const int c_end = min(m, c_begin + cols_per_split);
+    const int myrow = min(row0 + l31, n - 1);
+    const bool rowok = row0 + l31 < n;
 
-    float a[D / 2];
-    float rmr[16], xmr[16];
-    bool rok[16];
-    double sac[16], saa[16];
+    // issue one stage: PPW 1-KiB pieces per wave + the stage's TC column means
+    auto issue_stage = [&](int c0, float *vt, float *cms) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int P = wave * PPW + i, F = P * 64 + lane, r = F / CPR, p = F % CPR;
+            lds_dma16(V + (int64_t)min(c0 + r, m - 1) * D + 4 * (p ^ Sw::of(r)), vt + P * 256);
+        }
+        if (wave < CMW) {
+            const int c = wave * 64 + lane;
+            if (c < TC) lds_dma4(cm + min(c0 + c, m - 1), cms + wave * 64);
+        }
+    };
+    issue_stage(c_begin, vts[0], cmss[0]);
+
+    float u[D / 2];   // B operand: this lane's half of its U row (k index permuted: lane half h, step kk -> h*D/2+kk)
     {
-        const float *urow = U + (int64_t)min(row0 + l31, n - 1) * D + half * (D / 2);
+        const float *urow = U + (int64_t)myrow * D + half * (D / 2);
 #pragma unroll
         for (int q = 0; q < D / 8; ++q) {
             const float4 t = *reinterpret_cast<const float4 *>(urow + 4 * q);
-            a[4 * q + 0] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+            u[4 * q + 0] = t.x; u[4 * q + 1] = t.y; u[4 * q + 2] = t.z; u[4 * q + 3] = t.w;
         }
     }
+    float rmv = rm[myrow], xmv = xm[myrow];
+    // every load so far is consumed HERE, before the loop: left pending, the wait for it would sit in front of the
+    // first MFMA of every iteration (and, with an LDS-DMA in flight, be a full vmcnt(0))
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + tile_row(r, half);
-        rok[r] = row < n;
-        const int rc = min(row, n - 1);
-        rmr[r] = rm[rc];
-        xmr[r] = xm[rc];
-        sac[r] = 0.0;
-        saa[r] = 0.0;
-    }
-    double err2 = 0.0;
+    for (int k = 0; k < D / 2; ++k) asm volatile("" : "+v"(u[k]));
+    asm volatile("" : "+v"(rmv), "+v"(xmv));
+    const float *xrow = X + (int64_t)myrow * m;
+    const unsigned sw = (unsigned)Sw::of(l31);
+    double sac = 0.0, saa = 0.0, err2 = 0.0;
 
-    // this thread's share of a V stage: NLD 16-byte pieces, piece idx = tid + i*NT -> (row idx / (D/4), float4 idx % (D/4))
-    float4 stg[NLD];
-#define MFCD_LOAD_STAGE(C0)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
-        const int idx = tid + i * NT, r = idx / (D / 4), k4 = idx % (D / 4);                                 \
-        stg[i] = *reinterpret_cast<const float4 *>(V + (int64_t)min((C0) + r, m - 1) * D + 4 * k4);         \
-    }
-#define MFCD_STORE_STAGE(BUF)                                                                                \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                        \
-        const int idx = tid + i * NT, r = idx / (D / 4), k4 = idx % (D / 4);                                 \
-        *reinterpret_cast<float4 *>(vt + (size_t)(BUF) * TC * LD + r * LD + 4 * k4) = stg[i];                \
-    }
-    MFCD_LOAD_STAGE(c_begin)
-    MFCD_STORE_STAGE(0)
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     int buf = 0;
     for (int c0 = c_begin; c0 < c_end; c0 += TC) {
-        const bool has_next = c0 + TC < c_end;
-        if (has_next) { MFCD_LOAD_STAGE(c0 + TC) }
+        const float *vt = vts[buf], *cms = cmss[buf];
+        if (c0 + TC < c_end) issue_stage(c0 + TC, vts[buf ^ 1], cmss[buf ^ 1]);
         if (active) {
 #pragma unroll 1
             for (int j = 0; j < TC / 32; ++j) {
                 const int cb = c0 + 32 * j;
-                if (cb >= c_end) break;
-                const int col = cb + l31;
-                const bool cok = col < c_end;
-                const int cc = min(col, m - 1);
-                // X tile: scalar row base (rows past n are masked below, so any in-range row will do: clamp so that
-                // the +4 of the upper lane half stays inside) + one 32-bit lane offset
-                float x[16];
-                const unsigned xoff = (unsigned)(half * 4) * (unsigned)m + (unsigned)cc;
-                if (full_rows) {
+                if (cb >= c_end) continue;
+                const bool full = cb + 32 <= c_end;   // wave-uniform
+                // X values of this lane's row: columns cb + 8g + 4*half + {0,1,2,3}, g = 0..3
+                f32x4 xq[4];
+                if constexpr (XV) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float *xr = X + (int64_t)(row0 + tile_row(r, 0)) * m;
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = min(cb + 8 * g + 4 * half, m - 4);   // a 16-byte piece is wholly in or out
 #if MFCD_UVT_EXP == 1
-                        x[r] = (float)xoff;
+                        xq[g] = f32x4{(float)col, 1.f, 2.f, 3.f};
 #else
-                        x[r] = xr[xoff];
+                        xq[g] = *reinterpret_cast<const f32x4 *>(xrow + col);
 #endif
                     }
-                } else {   // last row tile of a ragged n: per-lane clamped rows (rows past n are masked below)
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) x[r] = X[(int64_t)min(row0 + tile_row(r, half), n - 1) * m + cc];
+                    for (int r = 0; r < 16; ++r) xq[r >> 2][r & 3] = xrow[min(cb + tile_row(r, half), m - 1)];
                 }
-                const float cmc = cm[cc];
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                const float *brow = vt + (size_t)buf * TC * LD + (32 * j + l31) * LD + half * (D / 2);
-                // B fragments from LDS in batches of QB 16-byte reads, one batch ahead of the MFMAs that consume them
-                // (the scheduling barrier keeps the compiler from hoisting every read to the top: 64+ registers)
+                // A fragments (V) from LDS in batches of QB 16-byte reads, one batch ahead of the MFMAs that consume
+                // them.  The reads are issued from inline asm with counted lgkmcnt waits: for a compiler-visible
+                // ds_read hipcc (ROCm 7.2) first drains EVERY outstanding LDS-DMA (s_waitcnt vmcnt(0)), i.e. the next
+                // stage issued just above, and the DMA would never overlap the MFMA chain.  LDS returns in order, so
+                // "at most QB operations outstanding" means the older batch has landed (extra operations the compiler
+                // may have in flight only make the wait stricter).
                 constexpr int QB = 4, NB = D / 8 / QB;
-                float4 t[2][QB];
+                const unsigned abase = lds_addr(vt + (32 * j + l31) * D);
+                f32x4 t[2][QB];
+                {
+                    const unsigned swb = opaque(sw);
 #pragma unroll
-                for (int q = 0; q < QB; ++q) t[0][q] = *reinterpret_cast<const float4 *>(brow + 4 * q);
+                    for (int q = 0; q < QB; ++q) lds_read16_issue(t[0][q], abase + 16u * ((half * (D / 8) + q) ^ swb));
+                }
 #pragma unroll
                 for (int bi = 0; bi < NB; ++bi) {
                     if (bi + 1 < NB) {
+                        const unsigned swb = opaque(sw);   // keeps the 32 read addresses from being hoisted into registers
 #pragma unroll
                         for (int q = 0; q < QB; ++q)
-                            t[(bi + 1) & 1][q] = *reinterpret_cast<const float4 *>(brow + 4 * ((bi + 1) * QB + q));
+                            lds_read16_issue(t[(bi + 1) & 1][q], abase + 16u * ((half * (D / 8) + (bi + 1) * QB + q) ^ swb));
+                        lds_wait4<QB>(t[bi & 1][0], t[bi & 1][1], t[bi & 1][2], t[bi & 1][3]);
+                    } else {
+                        lds_wait4<0>(t[bi & 1][0], t[bi & 1][1], t[bi & 1][2], t[bi & 1][3]);
                     }
 #pragma unroll
                     for (int q = 0; q < QB; ++q) {
-                        const float4 tq = t[bi & 1][q];
+                        const f32x4 tq = t[bi & 1][q];
                         const int k0 = 4 * (bi * QB + q);
 #if MFCD_UVT_EXP == 3
-                        acc[0] += a[k0] * tq.x + a[k0 + 1] * tq.y + a[k0 + 2] * tq.z + a[k0 + 3] * tq.w;
+                        acc[0] += u[k0] * tq.x + u[k0 + 1] * tq.y + u[k0 + 2] * tq.z + u[k0 + 3] * tq.w;
                         continue;
 #endif
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k0 + 0], tq.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k0 + 1], tq.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k0 + 2], tq.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k0 + 3], tq.w, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq.x, u[k0 + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq.y, u[k0 + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq.z, u[k0 + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq.w, u[k0 + 3], acc, 0, 0, 0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                // the X values become visible to the epilogue arithmetic only here: otherwise the scheduler moves
+                // x - xm, s*x up into the MFMA chain and with them the wait for the X loads (and, as an LDS-DMA is in
+                // flight, for everything: vmcnt(0)) to the top of the chain
+                // (tied to the accumulator so that it stays behind the last MFMA)
+                asm volatile("" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]));
+                // acc[4g+e] = (U V^T)[myrow][cb + 8g + 4*half + e]
+                const float *cmrow = cms + 32 * j + 4 * half;
+                float pac = 0.0f, paa = 0.0f, pe = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {   // branch-free: out-of-range rows / columns contribute exact zeros
-                    const bool ok = rok[r] && cok;
-                    const float g = acc[r];
-                    const float av = ok ? g - rmr[r] : 0.0f;             // structure.py:985
-                    const float cv = x[r] - xmr[r];                      // structure.py:987
-                    const float e = ok ? (g - cmc) - s * x[r] : 0.0f;    // structure.py:943, 949
+                for (int g = 0; g < 4; ++g) {
+                    const float4 c4 = *reinterpret_cast<const float4 *>(cmrow + 8 * g);
+                    const float cmv[4] = {c4.x, c4.y, c4.z, c4.w};
+                    const bool gok = full || cb + 8 * g + 4 * half < c_end;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        bool ok = gok;
+                        if constexpr (!XV) ok = full || cb + tile_row(r, half) < c_end;
+                        const float gv = acc[r];
+                        const float av = ok ? gv - rmv : 0.0f;                      // structure.py:985
+                        const float xv = xq[g][e];
+                        const float cv = xv - xmv;                                  // structure.py:987
+                        const float ev = ok ? (gv - cmv[e]) - s * xv : 0.0f;        // structure.py:943, 949
 #if MFCD_UVT_EXP == 2
-                    err2 += (double)(av + cv + e);
-                    continue;
+                        pe += av + cv + ev;
+                        continue;
 #endif
-                    sac[r] += (double)av * (double)cv;
-                    saa[r] += (double)av * (double)av;
-                    err2 += (double)e * (double)e;
+                        pac = fmaf(av, cv, pac);
+                        paa = fmaf(av, av, paa);
+                        pe = fmaf(ev, ev, pe);
+                    }
                 }
+                sac += (double)pac;
+                saa += (double)paa;
+                err2 += (double)pe;
             }
         }
-        if (has_next) { MFCD_STORE_STAGE(buf ^ 1) }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage have landed
+        __builtin_amdgcn_s_barrier();                      // ... and everybody's; this buffer may be overwritten
         buf ^= 1;
     }
-#undef MFCD_LOAD_STAGE
-#undef MFCD_STORE_STAGE
     if (!active) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-            sac[r] += __shfl_xor(sac[r], off, MFCD_WAVE);
-            saa[r] += __shfl_xor(saa[r], off, MFCD_WAVE);
-        }
-    }
+    // a row's columns are split over the two lane halves
+    sac += __shfl_xor(sac, 32, MFCD_WAVE);
+    saa += __shfl_xor(saa, 32, MFCD_WAVE);
+    if (!rowok) err2 = 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off, MFCD_WAVE);
-    if (l31 == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + tile_row(r, half);
-            if (row < n) {
-                double *o = part_rows + ((size_t)split * n + row) * 2;
-                o[0] = sac[r];
-                o[1] = saa[r];
-            }
-        }
+    if (half == 0 && rowok) {
+        double *o = part_rows + ((size_t)split * n + row0 + l31) * 2;
+        o[0] = sac;
+        o[1] = saa;
     }
     if (lane == 0) part_err[(size_t)split * ((n + 31) / 32) + rt] = err2;
 }
 
-// row_stats[r][8] and scal[4] from the partials (fixed order → deterministic)
+// row_stats[r][8] from the partials, plus this block's share of the two global sums (fixed order → deterministic):
+// blk[b] = {sum of part_err over the block's slice, sum of sxx over the block's rows}
 __global__ __launch_bounds__(256) void uvt_final_kernel(const double *__restrict__ part_rows,
                                                         const double *__restrict__ part_err,
                                                         const float *__restrict__ rm, const float *__restrict__ xm,
                                                         const double *__restrict__ scc, const double *__restrict__ sxx,
-                                                        int n, int splits, int n_err, double s,
-                                                        double *__restrict__ row_stats, double *__restrict__ scal)
+                                                        int n, int splits, int n_err,
+                                                        double *__restrict__ row_stats, double *__restrict__ blk)
 {
+    __shared__ double red[2][256];
     const int r = blockIdx.x * 256 + threadIdx.x;
+    double q = 0.0, e = 0.0;
     if (r < n) {
         double ac = 0.0, aa = 0.0;
         for (int sp = 0; sp < splits; ++sp) {
-            ac += part_rows[((size_t)sp * n + r) * 2 + 0];
-            aa += part_rows[((size_t)sp * n + r) * 2 + 1];
+            const double2 t = *reinterpret_cast<const double2 *>(part_rows + ((size_t)sp * n + r) * 2);
+            ac += t.x;
+            aa += t.y;
         }
+        q = sxx[r];
         double *o = row_stats + (size_t)r * 8;
         o[0] = ac; o[1] = aa; o[2] = scc[r]; o[3] = (double)rm[r]; o[4] = (double)xm[r];
-        o[5] = sxx[r]; o[6] = 0.0; o[7] = 0.0;
+        o[5] = q; o[6] = 0.0; o[7] = 0.0;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        double e = 0.0, q = 0.0;
-        for (int k = lane; k < n_err; k += MFCD_WAVE) e += part_err[k];
-        for (int k = lane; k < n; k += MFCD_WAVE) q += sxx[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            e += __shfl_xor(e, off, MFCD_WAVE);
-            q += __shfl_xor(q, off, MFCD_WAVE);
+    const int per = (n_err + gridDim.x - 1) / gridDim.x;
+    const int k1 = min(n_err, ((int)blockIdx.x + 1) * per);
+    for (int k = blockIdx.x * per + threadIdx.x; k < k1; k += 256) e += part_err[k];
+    red[0][threadIdx.x] = e;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
         }
-        if (lane == 0) {
-            scal[0] = e;
-            scal[1] = s * s * q;  // ||sX||_F^2  (structure.py:946)
-            scal[2] = 0.0;
-            scal[3] = 0.0;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        blk[2 * blockIdx.x + 0] = red[0][0];
+        blk[2 * blockIdx.x + 1] = red[1][0];
+    }
+}
+
+// scal[4] from the per-block shares (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void uvt_scal_kernel(const double *__restrict__ blk, int nblk, double s,
+                                                       double *__restrict__ scal)
+{
+    __shared__ double red[2][256];
+    double e = 0.0, q = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 256) {
+        e += blk[2 * k + 0];
+        q += blk[2 * k + 1];
+    }
+    red[0][threadIdx.x] = e;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
         }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        scal[0] = red[0][0];
+        scal[1] = s * s * red[1][0];  // ||sX||_F^2  (structure.py:946)
+        scal[2] = 0.0;
+        scal[3] = 0.0;
     }
 }
 
@@ -482,8 +616,8 @@ struct UvtWs {
     double *colpart;  // [2][kSlices][d]
     float *bar;       // [2][d]
     float *rm, *cm, *xm;
-    double *scc, *sxx, *part_rows, *part_err;
-    int splits, cols_per_split, n_err;
+    double *scc, *sxx, *part_rows, *part_err, *blk;
+    int splits, cols_per_split, n_err, nblk;
     size_t bytes;
 };
 
@@ -496,10 +630,10 @@ struct TiledCfg {
 TiledCfg tiled_cfg(int d)
 {
     switch (d) {
-    case 256: return {4, 32};    // A fragment = 128 registers: one wave per SIMD
-    case 128: return {8, 32};
-    case 64: return {8, 64};
-    case 32: return {8, 128};
+    case 256: return {4, 32};    // 64 KiB of stages: two workgroups (two waves per SIMD) per CU
+    case 128: return {4, 32};
+    case 64: return {4, 64};
+    case 32: return {4, 128};
     default: return {0, 0};
     }
 }
@@ -510,12 +644,12 @@ UvtWs plan_ws(char *base, int n, int m, int d)
     const int rtiles = (n + 31) / 32;
     const TiledCfg tc = n >= 32 ? tiled_cfg(d) : TiledCfg{0, 0};
     if (tc.NW) {
-        // tiled form: >= ~3 workgroups per CU in total, a split's V rows small enough for one XCD's L2 (4 MiB),
-        // >= 2 stages per split; 8 or more splits (a multiple of 8 where the column count allows) so that the
-        // XCD-aware mapping applies
+        // tiled form: several rounds of workgroups over the chip (the hardware balances them), a split's V rows
+        // small enough for one XCD's L2 (4 MiB), >= 2 stages per split; 8 or more splits (a multiple of 8 where the
+        // column count allows) so that the XCD-aware mapping applies
         const int row_blocks = (n + tc.NW * 32 - 1) / (tc.NW * 32);
         const int stages = (m + tc.TC - 1) / tc.TC;
-        int64_t want = (768 + row_blocks - 1) / row_blocks;
+        int64_t want = (4096 + row_blocks - 1) / row_blocks;
         const int64_t by_l2 = ((int64_t)m * d * 4 + (2 << 20) - 1) / (2 << 20);
         if (by_l2 > want) want = by_l2;
         int splits = want <= 1 ? 1 : (int)((want + 7) / 8 * 8);
@@ -536,6 +670,7 @@ UvtWs plan_ws(char *base, int n, int m, int d)
         w.splits = (m + w.cols_per_split - 1) / w.cols_per_split;
     }
     w.n_err = w.splits * rtiles;
+    w.nblk = (n + 255) / 256;
     size_t off = 0;
     auto take = [&](size_t b) { char *p = base ? base + off : nullptr; off += al(b); return p; };
     w.colpart = (double *)take(sizeof(double) * 2 * kSlices * (size_t)d);
@@ -547,8 +682,24 @@ UvtWs plan_ws(char *base, int n, int m, int d)
     w.sxx = (double *)take(sizeof(double) * (size_t)n);
     w.part_rows = (double *)take(sizeof(double) * 2 * (size_t)n * w.splits);
     w.part_err = (double *)take(sizeof(double) * (size_t)w.n_err);
+    w.blk = (double *)take(sizeof(double) * 2 * (size_t)w.nblk);
     w.bytes = off;
     return w;
+}
+
+template <int DD, int NW, int TC>
+int launch_tiled(const UvtWs &w, const float *U, const float *V, const float *X, int n, int m, float s, bool xv,
+                 hipStream_t st)
+{
+    const int row_blocks = (n + NW * 32 - 1) / (NW * 32);
+    const unsigned blocks = (unsigned)row_blocks * (w.splits >= 8 ? 8u * ((w.splits + 7) / 8) : (unsigned)w.splits);
+    if (xv)
+        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
+                           w.cm, w.xm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
+    else
+        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, false>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
+                           w.cm, w.xm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
+    return 0;
 }
 
 }  // namespace
@@ -567,32 +718,23 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
     const UvtWs w = plan_ws((char *)workspace, n, m, d);
     if (workspace_bytes < w.bytes) return MFCD_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    const bool xv = (reinterpret_cast<uintptr_t>(X) & 15u) == 0 && m % 4 == 0;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(kSlices, 2), dim3(256), 0, st, U, V, n, m, d, w.colpart);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256, 2), dim3(256), 0, st, w.colpart, n, m, d, w.bar);
     hipLaunchKernelGGL(centre_vectors_kernel, dim3((unsigned)(((int64_t)n + m + 3) / 4)), dim3(256), 0, st, U, V,
                        w.bar, n, m, d, w.rm, w.cm);
-    hipLaunchKernelGGL(x_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
+    if (xv) hipLaunchKernelGGL(x_rows_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
+    else hipLaunchKernelGGL(x_rows_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
     const dim3 grid(((n + 31) / 32 + 3) / 4, w.splits);
     const bool al16 = ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15u) == 0;
     const TiledCfg tc = n >= 32 ? tiled_cfg(d) : TiledCfg{0, 0};
 #define MFCD_UVT(DD)                                                                                            \
     hipLaunchKernelGGL((uvt_main_kernel<DD>), grid, dim3(256), 0, st, U, V, X, w.rm, w.cm, w.xm, n, m, d, (float)s, \
                        w.cols_per_split, w.part_rows, w.part_err)
-#define MFCD_UVT_TILED(DD, NW, TC)                                                                               \
-    do {                                                                                                         \
-        const int row_blocks = (n + NW * 32 - 1) / (NW * 32);                                                    \
-        const unsigned blocks = (unsigned)row_blocks * (w.splits >= 8 ? 8u * ((w.splits + 7) / 8) : (unsigned)w.splits); \
-        const size_t lds = sizeof(float) * 2 * TC * (DD + 4);                                                    \
-        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)uvt_tiled_kernel<DD, NW, TC>,                             \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC>), dim3(blocks), dim3(NW * 64), lds, st, U, V, X, w.rm,   \
-                           w.cm, w.xm, n, m, (float)s, w.cols_per_split, w.splits, row_blocks, w.part_rows,      \
-                           w.part_err);                                                                          \
-    } while (0)
-    if (al16 && tc.NW && d == 256) MFCD_UVT_TILED(256, 4, 32);
-    else if (al16 && tc.NW && d == 128) MFCD_UVT_TILED(128, 8, 32);
-    else if (al16 && tc.NW && d == 64) MFCD_UVT_TILED(64, 8, 64);
-    else if (al16 && tc.NW && d == 32) MFCD_UVT_TILED(32, 8, 128);
+    if (al16 && tc.NW && d == 256) { const int rc = launch_tiled<256, 4, 32>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+    else if (al16 && tc.NW && d == 128) { const int rc = launch_tiled<128, 4, 32>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+    else if (al16 && tc.NW && d == 64) { const int rc = launch_tiled<64, 4, 64>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+    else if (al16 && tc.NW && d == 32) { const int rc = launch_tiled<32, 4, 128>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
     else if (al16 && d == 8) MFCD_UVT(8);
     else if (al16 && d == 16) MFCD_UVT(16);
     else if (al16 && d == 32) MFCD_UVT(32);
@@ -601,9 +743,9 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
     else if (al16 && d == 256) MFCD_UVT(256);
     else MFCD_UVT(0);
 #undef MFCD_UVT
-#undef MFCD_UVT_TILED
-    hipLaunchKernelGGL(uvt_final_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, w.xm,
-                       w.scc, w.sxx, n, w.splits, w.n_err, s, row_stats, scal);
+    hipLaunchKernelGGL(uvt_final_kernel, dim3(w.nblk), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, w.xm, w.scc,
+                       w.sxx, n, w.splits, w.n_err, row_stats, w.blk);
+    hipLaunchKernelGGL(uvt_scal_kernel, dim3(1), dim3(256), 0, st, w.blk, w.nblk, s, scal);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }
