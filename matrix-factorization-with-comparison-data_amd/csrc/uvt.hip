@@ -23,6 +23,16 @@
 #define MFCD_UVT_EXP 0   // diagnostic builds only (tools/): 1 no X loads, 2 no f64 epilogue, 3 no MFMA
 #endif
 
+#ifndef MFCD_UVT_STAMPS
+#define MFCD_UVT_STAMPS 0   // diagnostic builds only (tools/diag_uvt_stamps.py): in-kernel cycle accounting per phase
+#endif
+#if MFCD_UVT_STAMPS
+__device__ unsigned long long mfcd_uvt_dbg[8];   // chain, epilogue, sync, dma-issue cycles; tiles; waves
+#define MFCD_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define MFCD_STAMP(var)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -284,41 +294,56 @@ __global__ __launch_bounds__(256) void uvt_main_kernel(const float *__restrict__
 //
 // A workgroup of NW waves owns NW*32 rows of U; the columns of its split arrive as TC-column stages of V in LDS,
 // once per WORKGROUP, written by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass),
-// double-buffered, one barrier per stage.  The LDS image of a stage is the plain [TC][D] array with the 16-byte
-// chunks of every row XOR-permuted (chunk p of row r holds logical chunk p ^ swz(r)); the permutation is applied
-// to the per-lane SOURCE address of the DMA and undone in the fragment read address, and makes the per-lane
-// 16-byte fragment reads (lane = column, stride = one row) conflict-free in every 16-lane group of ds_read_b128.
+// double-buffered, one barrier per stage.  A stage is the plain [TC][D] array cut into 1-KiB pieces (one wave-level
+// DMA instruction each: the source of piece P is simply the P-th KiB of the stage's V rows) with 16 bytes of padding
+// after every piece, which spreads the per-lane 16-byte fragment reads (lane = column, stride = one row) over the
+// banks: conflict-free at D = 256 (one row per piece), 1024/(4D)-way below, where LDS time does not matter.  A lane's
+// fragment chunks are consecutive, so all reads of a tile share one address register (immediate offsets).
 //
 // Each wave computes the TRANSPOSED tile: V rows are the MFMA's A operand, the wave's 32 U rows (registers, for
 // the whole sweep) its B operand, so that in the accumulator layout a lane holds ONE row of U V^T and 16 of its
 // columns (4 runs of 4 consecutive columns).  Per-row sums are then per-lane scalars (no 16-wide f64 accumulator
 // arrays) and the matching X values are four 16-byte loads per lane.  Inside a tile the epilogue sums its 16
-// terms in fp32 (explicit fmaf), across tiles in f64.
-template <int D> struct StageSwz {
-    static constexpr int CPR = D / 4;                       // 16-byte chunks per row
-    static constexpr int RP = CPR >= 16 ? 1 : 16 / CPR;     // rows per 256-byte bank span
-    __device__ static __forceinline__ int of(int r) { return CPR >= 16 ? (r & 15) : ((r / RP) & (CPR - 1)); }
-};
+// terms in fp32 (packed two-wide), across tiles in f64.
+//
+// The f32 MFMA runs on the SIMD's vector lanes: other waves' VALU work does not hide under it (in-kernel stamps:
+// an epilogue beside another wave's chain takes 10x its issue time), so what counts is the number of non-MFMA
+// vector instructions per tile; hence the immediate-offset addressing and the packed epilogue.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void lds_dma16(const float *src, float *lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_dma4(const float *src, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+}
 __device__ __forceinline__ unsigned lds_addr(const float *p)
 {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
 }
-__device__ __forceinline__ unsigned opaque(unsigned x)
-{
-    asm volatile("" : "+v"(x));
-    return x;
-}
-// 16-byte LDS read issued without the compiler's wait bookkeeping; pair with lds_wait4 before the first use.
+// 16-byte LDS read issued without the compiler's wait bookkeeping (immediate byte offset); pair with lds_wait4.
+template <int OFF>
 __device__ __forceinline__ void lds_read16_issue(f32x4 &dst, unsigned byte_addr)
 {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(byte_addr) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(byte_addr), "n"(OFF) : "memory");
+}
+// the QB reads of batch `bi` (compile-time after unrolling): byte offsets 16*(QB*bi + q)
+template <int QB>
+__device__ __forceinline__ void lds_read16_next(f32x4 (&t)[QB], unsigned abase, int bi)
+{
+    static_assert(QB == 4, "batch of four reads");
+    switch (bi) {   // folded: bi is a constant in the unrolled caller
+#define MFCD_B(B) case B: lds_read16_issue<64 * B>(t[0], abase); lds_read16_issue<64 * B + 16>(t[1], abase); \
+                  lds_read16_issue<64 * B + 32>(t[2], abase); lds_read16_issue<64 * B + 48>(t[3], abase); break;
+        MFCD_B(1) MFCD_B(2) MFCD_B(3) MFCD_B(4) MFCD_B(5) MFCD_B(6) MFCD_B(7)
+#undef MFCD_B
+    default: break;
+    }
 }
 // wait until at most N LDS operations are outstanding; the operands tie the consumers to the wait
 template <int N>
@@ -326,26 +351,18 @@ __device__ __forceinline__ void lds_wait4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d
 {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
-__device__ __forceinline__ void lds_dma4(const float *src, float *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
-}
 
 template <int D, int NW, int TC, bool XV>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(D >= 256 ? 2 : 3)))
-void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
-                                                            const float *__restrict__ X, const float *__restrict__ rm,
-                                                            const float *__restrict__ cm, const float *__restrict__ xm,
-                                                            int n, int m, float s, int cols_per_split, int splits,
-                                                            int row_blocks, double *__restrict__ part_rows,
-                                                            double *__restrict__ part_err)
+void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ X,
+                      const float *__restrict__ rm, const float *__restrict__ cm, const float *__restrict__ xm, int n,
+                      int m, float s, int cols_per_split, int splits, int row_blocks, double *__restrict__ part_rows,
+                      double *__restrict__ part_err)
 {
-    using Sw = StageSwz<D>;
-    constexpr int CPR = Sw::CPR, PIECES = TC * D / 256, PPW = PIECES / NW, CMW = (TC + 63) / 64;
+    constexpr int CPR = D / 4, PIECES = TC * D / 256, PPW = PIECES / NW, CMW = (TC + 63) / 64, PF = 260;
     static_assert(PIECES % NW == 0 && TC % 32 == 0 && CMW <= NW, "stage must split evenly over the waves");
-    __shared__ __attribute__((aligned(16))) float vts[2][TC * D];     // [buffer][TC][D], chunks permuted
-    __shared__ __attribute__((aligned(16))) float cmss[2][CMW * 64];  // column means of U V^T for the stage's columns
+    __shared__ __attribute__((aligned(16))) float vts[2][PIECES * PF];   // [buffer][piece][256 + 4 pad]
+    __shared__ __attribute__((aligned(16))) float cmss[2][CMW * 64];      // column means of U V^T, stage's columns
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int split, rb;
@@ -365,12 +382,19 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
     const int myrow = min(row0 + l31, n - 1);
     const bool rowok = row0 + l31 < n;
 
-    // issue one stage: PPW 1-KiB pieces per wave + the stage's TC column means
+    // issue one stage: PPW 1-KiB pieces per wave (piece P = floats [256 P, 256 P + 256) of the stage's V rows; the host
+    // guarantees m*D < 2^31) + the stage's TC column means
+    const int vlast = m * D - 4;
+    const int dma0 = (wave * PPW * 64 + lane) * 4;
     auto issue_stage = [&](int c0, float *vt, float *cms) {
+        const int base = c0 * D + dma0;
+        if (c0 + TC <= m) {
+            const float *vb = V + base;   // one 64-bit address per stage, the pieces are 1 KiB apart
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int P = wave * PPW + i, F = P * 64 + lane, r = F / CPR, p = F % CPR;
-            lds_dma16(V + (int64_t)min(c0 + r, m - 1) * D + 4 * (p ^ Sw::of(r)), vt + P * 256);
+            for (int i = 0; i < PPW; ++i) lds_dma16(vb + i * 256, vt + (wave * PPW + i) * PF);
+        } else {   // ragged last stage: rows past m are never used, read something in range instead
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) lds_dma16(V + min(base + i * 256, vlast), vt + (wave * PPW + i) * PF);
         }
         if (wave < CMW) {
             const int c = wave * 64 + lane;
@@ -394,36 +418,49 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
 #pragma unroll
     for (int k = 0; k < D / 2; ++k) asm volatile("" : "+v"(u[k]));
     asm volatile("" : "+v"(rmv), "+v"(xmv));
-    const float *xrow = X + (int64_t)myrow * m;
-    const unsigned sw = (unsigned)Sw::of(l31);
+    const float *xlane = X + (int64_t)myrow * m + 4 * half;   // + cb + 8g: this lane's 16-byte pieces of a tile
+    // fragment address of tile j of a stage: row 32j + l31, chunks half*CPR/2 + q (one piece, consecutive)
+    const int f0 = l31 * CPR + half * (CPR / 2);
+    const unsigned frag0 = (unsigned)(((f0 >> 6) * PF + (f0 & 63) * 4) * 4);          // bytes, tile 0
+    constexpr unsigned frag_step = (unsigned)((32 * CPR / 64) * PF * 4);              // bytes per tile (32 rows)
     double sac = 0.0, saa = 0.0, err2 = 0.0;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+#if MFCD_UVT_STAMPS
+    unsigned long long cyc_chain = 0, cyc_epi = 0, cyc_sync = 0, cyc_dma = 0, n_tiles = 0;
+#endif
     int buf = 0;
     for (int c0 = c_begin; c0 < c_end; c0 += TC) {
-        const float *vt = vts[buf], *cms = cmss[buf];
+        const float *cms = cmss[buf];
+        MFCD_STAMP(td0);
         if (c0 + TC < c_end) issue_stage(c0 + TC, vts[buf ^ 1], cmss[buf ^ 1]);
+        MFCD_STAMP(td1);
+#if MFCD_UVT_STAMPS
+        cyc_dma += td1 - td0;
+#endif
         if (active) {
 #pragma unroll 1
             for (int j = 0; j < TC / 32; ++j) {
                 const int cb = c0 + 32 * j;
                 if (cb >= c_end) continue;
                 const bool full = cb + 32 <= c_end;   // wave-uniform
+                MFCD_STAMP(tt0);
                 // X values of this lane's row: columns cb + 8g + 4*half + {0,1,2,3}, g = 0..3
                 f32x4 xq[4];
-                if constexpr (XV) {
+                if (XV && full) {
+                    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xlane + cb);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int col = min(cb + 8 * g + 4 * half, m - 4);   // a 16-byte piece is wholly in or out
 #if MFCD_UVT_EXP == 1
-                        xq[g] = f32x4{(float)col, 1.f, 2.f, 3.f};
+                        xq[g] = f32x4{(float)cb, 1.f, 2.f, 3.f};
 #else
-                        xq[g] = *reinterpret_cast<const f32x4 *>(xrow + col);
+                        xq[g] = xp[2 * g];
 #endif
                     }
                 } else {
+                    const float *xrow = xlane - 4 * half;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) xq[r >> 2][r & 3] = xrow[min(cb + tile_row(r, half), m - 1)];
                 }
@@ -437,20 +474,16 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
                 // "at most QB operations outstanding" means the older batch has landed (extra operations the compiler
                 // may have in flight only make the wait stricter).
                 constexpr int QB = 4, NB = D / 8 / QB;
-                const unsigned abase = lds_addr(vt + (32 * j + l31) * D);
+                const unsigned abase = lds_addr(vts[buf]) + frag0 + (unsigned)j * frag_step;
                 f32x4 t[2][QB];
-                {
-                    const unsigned swb = opaque(sw);
-#pragma unroll
-                    for (int q = 0; q < QB; ++q) lds_read16_issue(t[0][q], abase + 16u * ((half * (D / 8) + q) ^ swb));
-                }
+                lds_read16_issue<0>(t[0][0], abase);
+                lds_read16_issue<16>(t[0][1], abase);
+                lds_read16_issue<32>(t[0][2], abase);
+                lds_read16_issue<48>(t[0][3], abase);
 #pragma unroll
                 for (int bi = 0; bi < NB; ++bi) {
                     if (bi + 1 < NB) {
-                        const unsigned swb = opaque(sw);   // keeps the 32 read addresses from being hoisted into registers
-#pragma unroll
-                        for (int q = 0; q < QB; ++q)
-                            lds_read16_issue(t[(bi + 1) & 1][q], abase + 16u * ((half * (D / 8) + (bi + 1) * QB + q) ^ swb));
+                        lds_read16_next<QB>(t[(bi + 1) & 1], abase, bi + 1);
                         lds_wait4<QB>(t[bi & 1][0], t[bi & 1][1], t[bi & 1][2], t[bi & 1][3]);
                     } else {
                         lds_wait4<0>(t[bi & 1][0], t[bi & 1][1], t[bi & 1][2], t[bi & 1][3]);
@@ -469,6 +502,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq.w, u[k0 + 3], acc, 0, 0, 0);
                     }
                 }
+                MFCD_STAMP(tt1);
                 // the X values become visible to the epilogue arithmetic only here: otherwise the scheduler moves
                 // x - xm, s*x up into the MFMA chain and with them the wait for the X loads (and, as an LDS-DMA is in
                 // flight, for everything: vmcnt(0)) to the top of the chain
@@ -476,26 +510,43 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
                 asm volatile("" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]));
                 // acc[4g+e] = (U V^T)[myrow][cb + 8g + 4*half + e]
                 const float *cmrow = cms + 32 * j + 4 * half;
-                float pac = 0.0f, paa = 0.0f, pe = 0.0f;
+                float pac, paa, pe;
+                if (full) {   // two terms per instruction (v_pk_*_f32)
+                    const f32x2 rm2 = {rmv, rmv}, xm2 = {xmv, xmv}, s2 = {s, s};
+                    f32x2 pac2 = {0.0f, 0.0f}, paa2 = {0.0f, 0.0f}, pe2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 c4 = *reinterpret_cast<const float4 *>(cmrow + 8 * g);
-                    const float cmv[4] = {c4.x, c4.y, c4.z, c4.w};
-                    const bool gok = full || cb + 8 * g + 4 * half < c_end;
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cmrow + 8 * g);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        bool ok = gok;
-                        if constexpr (!XV) ok = full || cb + tile_row(r, half) < c_end;
-                        const float gv = acc[r];
-                        const float av = ok ? gv - rmv : 0.0f;                      // structure.py:985
-                        const float xv = xq[g][e];
-                        const float cv = xv - xmv;                                  // structure.py:987
-                        const float ev = ok ? (gv - cmv[e]) - s * xv : 0.0f;        // structure.py:943, 949
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x2 g2 = {acc[4 * g + 2 * h], acc[4 * g + 2 * h + 1]};
+                            const f32x2 x2 = {xq[g][2 * h], xq[g][2 * h + 1]};
+                            const f32x2 c2 = {c4[2 * h], c4[2 * h + 1]};
+                            const f32x2 av = g2 - rm2;                         // structure.py:985
+                            const f32x2 cv = x2 - xm2;                         // structure.py:987
+                            const f32x2 ev = (g2 - c2) - s2 * x2;              // structure.py:943, 949
 #if MFCD_UVT_EXP == 2
-                        pe += av + cv + ev;
-                        continue;
+                            pe2 += av + cv + ev;
+                            continue;
 #endif
+                            pac2 = __builtin_elementwise_fma(av, cv, pac2);
+                            paa2 = __builtin_elementwise_fma(av, av, paa2);
+                            pe2 = __builtin_elementwise_fma(ev, ev, pe2);
+                        }
+                    }
+                    pac = pac2.x + pac2.y;
+                    paa = paa2.x + paa2.y;
+                    pe = pe2.x + pe2.y;
+                } else {      // ragged last tile of the split: per-term column masks
+                    pac = paa = pe = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = cb + tile_row(r, half) < c_end;
+                        const float gv = acc[r], xv = xq[r >> 2][r & 3];
+                        const float cmv = cmrow[8 * (r >> 2) + (r & 3)];
+                        const float av = ok ? gv - rmv : 0.0f;
+                        const float cv = xv - xmv;
+                        const float ev = ok ? (gv - cmv) - s * xv : 0.0f;
                         pac = fmaf(av, cv, pac);
                         paa = fmaf(av, av, paa);
                         pe = fmaf(ev, ev, pe);
@@ -504,12 +555,34 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V,
                 sac += (double)pac;
                 saa += (double)paa;
                 err2 += (double)pe;
+#if MFCD_UVT_STAMPS
+                asm volatile("" : "+v"(sac), "+v"(saa), "+v"(err2));
+                MFCD_STAMP(tt2);
+                cyc_chain += tt1 - tt0;
+                cyc_epi += tt2 - tt1;
+                n_tiles += 1;
+#endif
             }
         }
+        MFCD_STAMP(ts0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage have landed
         __builtin_amdgcn_s_barrier();                      // ... and everybody's; this buffer may be overwritten
+        MFCD_STAMP(ts1);
+#if MFCD_UVT_STAMPS
+        cyc_sync += ts1 - ts0;
+#endif
         buf ^= 1;
     }
+#if MFCD_UVT_STAMPS
+    if (lane == 0 && active) {
+        atomicAdd(&mfcd_uvt_dbg[0], cyc_chain);
+        atomicAdd(&mfcd_uvt_dbg[1], cyc_epi);
+        atomicAdd(&mfcd_uvt_dbg[2], cyc_sync);
+        atomicAdd(&mfcd_uvt_dbg[3], cyc_dma);
+        atomicAdd(&mfcd_uvt_dbg[4], n_tiles);
+        atomicAdd(&mfcd_uvt_dbg[5], 1ull);
+    }
+#endif
     if (!active) return;
     // a row's columns are split over the two lane halves
     sac += __shfl_xor(sac, 32, MFCD_WAVE);
@@ -642,7 +715,7 @@ UvtWs plan_ws(char *base, int n, int m, int d)
 {
     UvtWs w;
     const int rtiles = (n + 31) / 32;
-    const TiledCfg tc = n >= 32 ? tiled_cfg(d) : TiledCfg{0, 0};
+    const TiledCfg tc = n >= 32 && (int64_t)m * d < (int64_t)0x7fff0000 ? tiled_cfg(d) : TiledCfg{0, 0};
     if (tc.NW) {
         // tiled form: several rounds of workgroups over the chip (the hardware balances them), a split's V rows
         // small enough for one XCD's L2 (4 MiB), >= 2 stages per split; 8 or more splits (a multiple of 8 where the
@@ -727,7 +800,7 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
     else hipLaunchKernelGGL(x_rows_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
     const dim3 grid(((n + 31) / 32 + 3) / 4, w.splits);
     const bool al16 = ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15u) == 0;
-    const TiledCfg tc = n >= 32 ? tiled_cfg(d) : TiledCfg{0, 0};
+    const TiledCfg tc = n >= 32 && (int64_t)m * d < (int64_t)0x7fff0000 ? tiled_cfg(d) : TiledCfg{0, 0};
 #define MFCD_UVT(DD)                                                                                            \
     hipLaunchKernelGGL((uvt_main_kernel<DD>), grid, dim3(256), 0, st, U, V, X, w.rm, w.cm, w.xm, n, m, d, (float)s, \
                        w.cols_per_split, w.part_rows, w.part_err)
@@ -749,6 +822,18 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }
+
+#if MFCD_UVT_STAMPS
+// diagnostic build only: read and clear the in-kernel cycle accounting (not declared in include/mfcd.h)
+extern "C" int mfcd_uvt_debug_read(unsigned long long *out8_host)
+{
+    MFCD_HIP_TRY(hipDeviceSynchronize());
+    MFCD_HIP_TRY(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(mfcd_uvt_dbg), 8 * sizeof(unsigned long long)));
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    MFCD_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mfcd_uvt_dbg), zero, sizeof(zero)));
+    return 0;
+}
+#endif
 
 extern "C" int mfcd_uvt_rows(const float *U, const float *V, const int32_t *row_ids, int k, int n, int m, int d,
                              float *out, void *stream)
