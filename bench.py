@@ -211,9 +211,10 @@ def _run():
     ap.add_argument("--steps", type=int, default=10490)   # 10 epochs of C2
     ap.add_argument("--warmup", type=int, default=1049)   # 1 epoch
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dp-mode", choices=["allgather", "allreduce"], default=None,
-                    help="exchange form of the data-parallel path (default allgather); given with --gpus 1 it "
-                         "rehearses that path on a one-rank group")
+    ap.add_argument("--dp-mode", choices=["native", "allgather", "allreduce"], default=None,
+                    help="form of the data-parallel path (default native: the loop inside libmfcd_hip.so with one RCCL "
+                         "all-gather per step; allgather / allreduce: the per-step torch.distributed loops); given "
+                         "with --gpus 1 it rehearses that path on a one-rank group")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -236,7 +237,7 @@ def _run():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
-        out = mdist.bench_data_parallel(cfg, dev, args.steps, args.warmup, args.seed, mode=args.dp_mode or "allgather")
+        out = mdist.bench_data_parallel(cfg, dev, args.steps, args.warmup, args.seed, mode=args.dp_mode or "native")
         dist.destroy_process_group()
         return out, rank == 0
 

@@ -36,6 +36,7 @@ extern "C" {
 #define MFCD_EWORKSPACE (-2) /* workspace smaller than mfcd_*_workspace_bytes says             */
 #define MFCD_EALIGN (-3)   /* a table pointer is not 4-byte aligned                            */
 #define MFCD_EINDEX (-4)   /* a sample indexes outside [0,n) x [0,m)^2 (mfcd_check_samples)     */
+#define MFCD_ERCCL (-5)    /* RCCL is not loadable in this process, or an RCCL call failed      */
 
 #define MFCD_MAX_D 1024
 
@@ -179,6 +180,33 @@ int mfcd_adam_dense(float *U, float *V, float *mU, float *vU, float *mV, float *
                     const float *gradU, const float *gradV, int64_t step, int n, int m, int d,
                     double lr, double beta1, double beta2, double eps, double weight_decay,
                     void *stream);
+
+/*
+ * Data-parallel training loop, native (one process per GPU; RCCL is bound at run time, the library has no link-time
+ * dependency on it).  Sharding as SURVEY section 8e: a GLOBAL batch of B*world samples per optimiser step, rank r owns
+ * the contiguous slice [r*B, (r+1)*B) of it, the divisor of the mean is the global batch size, every rank applies the
+ * same gathered quantities in the same order, so replicas stay bit-identical and the run equals the single-GPU run
+ * with batch_size = B*world (structure.py:840-852 with a larger DataLoader batch).  Per step: one coefficient
+ * kernel over the rank's shard, ONE in-place ncclAllGather of B {g_t, BCE term_t} float pairs per rank, one fused
+ * step kernel over the global batch; everything is enqueued on `stream`, nothing synchronises the host.
+ *
+ *   mfcd_dp_unique_id      rank 0: fills a 128-byte ncclUniqueId, which the caller distributes to the other ranks
+ *   mfcd_dp_comm_create    every rank (current HIP device): ncclCommInitRank -> opaque communicator handle
+ *   mfcd_dp_comm_destroy
+ *   mfcd_dp_train_steps    `samples` is the GLOBAL stream of N samples (identical on every rank);
+ *                          loss_per_step[k] = mean BCE of global batch k (identical on every rank);
+ *                          comm == NULL: no collective is issued and this process computes every rank's shard
+ *                          itself (exact, because replicas are identical): single-process rehearsal of any world
+ *                          size, and the whole of the work when world == 1.
+ */
+int mfcd_dp_unique_id(void *id_out, size_t id_bytes);
+int mfcd_dp_comm_create(const void *id, size_t id_bytes, int rank, int world, void **comm_out);
+int mfcd_dp_comm_destroy(void *comm);
+size_t mfcd_dp_workspace_bytes(int64_t N, int B, int world, int n, int m, int d);
+int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                        const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0, int n,
+                        int m, int d, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        float *loss_per_step, void *workspace, size_t workspace_bytes, void *comm, void *stream);
 
 /*
  * Dense UV^T pass against X [n][m] fp32 without materialising UV^T (MFMA fp32 tiles, fused

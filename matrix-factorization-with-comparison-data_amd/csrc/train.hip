@@ -15,10 +15,12 @@
 //   HBM traffic per element is the 24-byte minimum: read p,m,v, write p,m,v.
 //
 // Roofline: HBM-bound streaming; algorithmic bytes per step = 24*(n+m)*d + 12*B*d + 16*B.
+#include <cstring>
 #include <mutex>
 #include <vector>
 
 #include "common.h"
+#include "rccl_dyn.h"
 #include "train_common.h"
 
 namespace {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void train_step_kernel(
     TP *__restrict__ Vout, float *__restrict__ mU, float *__restrict__ vU, float *__restrict__ mV,
     float *__restrict__ vV, const mfcd_sample *__restrict__ batch, const float *__restrict__ g_in,
     int Bk, float inv_batch, int n, int m, int d, int blocksU, AdamConst ac,
-    float *__restrict__ loss_terms, float *__restrict__ Gu, float *__restrict__ Gv)
+    float *__restrict__ loss_terms, float *__restrict__ Gu, float *__restrict__ Gv, int g_stride)
 {
     constexpr int E = 256 * VEC * CHUNKS;
     extern __shared__ __attribute__((aligned(16))) float sg[];  // [(row_hi-row_lo)*d] sparse row gradients
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void train_step_kernel(
                 const TP *ur = Uin + (int64_t)uu * d, *vi = Vin + (int64_t)ii * d, *vj = Vin + (int64_t)jj * d;
                 float g;
                 if (g_in) {
-                    g = g_in[base + tl];
+                    g = g_in[(base + tl) * g_stride];   // stride 2: interleaved {g, term} pairs of the DP exchange
                 } else {
                     float acc = 0.0f;
                     for (int k = lane; k < d; k += MFCD_WAVE) acc += ldf(ur, k) * (ldf(vi, k) - ldf(vj, k));
@@ -251,6 +253,39 @@ __global__ __launch_bounds__(256) void coeff_kernel(const float *__restrict__ U,
     }
 }
 
+// Data-parallel exchange slot of one rank for one step: B interleaved pairs {g_t, BCE term_t}; one wave per slot entry.
+// Entries past the rank's (possibly short or empty) shard are written as {0, 0} so that the gathered buffer of a
+// step is fully defined.
+__global__ __launch_bounds__(256) void dp_coeff_kernel(const float *__restrict__ U, const float *__restrict__ V,
+                                                       const mfcd_sample *__restrict__ shard, int myB, int B, int d,
+                                                       float inv_batch, float2 *__restrict__ slot)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= B) return;
+    if (t >= myB) {
+        if (lane == 0) slot[t] = make_float2(0.0f, 0.0f);
+        return;
+    }
+    const mfcd_sample s = shard[t];
+    const float p = sigmoid_f32(wave_score(U, V, s.u, s.i, s.j, d, lane));
+    if (lane == 0) slot[t] = make_float2(bce_sigmoid_backward_f32(p, s.z, inv_batch), bce_term_f32(p, s.z));
+}
+
+// out[k] = mean of the BCE terms of global batch k from the gathered exchange buffer xbuf[k][world*B] (pairs);
+// one wave per step, fixed summation order (identical on every rank).
+__global__ __launch_bounds__(64) void dp_loss_kernel(const float2 *__restrict__ xbuf, int64_t N, int Bg,
+                                                     float *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int64_t off = (int64_t)blockIdx.x * Bg;
+    const int b = (int)((N - off) < Bg ? (N - off) : Bg);
+    float acc = 0.0f;
+    for (int t = lane; t < b; t += MFCD_WAVE) acc += xbuf[off + t].y;
+    acc = wave_sum64(acc);
+    if (lane == 0) out[blockIdx.x] = acc / (float)b;
+}
+
 // out[k] = mean(terms[k*B .. min((k+1)*B,N))) — one wave per batch, fixed summation order.
 // With `samples` set, terms[] holds sigmoid outputs p and the BCE term is formed here from p and the label
 // (the resident kernel keeps the logs off its critical path); otherwise terms[] holds ready BCE terms.
@@ -323,23 +358,24 @@ AdamConst adam_const(double lr, double beta1, double beta2, double eps, double w
 template <int VEC, int CHUNKS, int MODE, typename TP>
 void launch_step(const Plan &pl, hipStream_t st, const TP *Uin, const TP *Vin, TP *Uout, TP *Vout,
                  float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
-                 float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu, float *Gv)
+                 float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu, float *Gv,
+                 int g_stride)
 {
     hipLaunchKernelGGL((train_step_kernel<VEC, CHUNKS, MODE, TP>), dim3(pl.blocksU + pl.blocksV), dim3(256), pl.lds, st,
                        Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, m, d, pl.blocksU, ac,
-                       loss_terms, Gu, Gv);
+                       loss_terms, Gu, Gv, g_stride);
 }
 
 template <int MODE = 0, typename TP = float>
 void dispatch_step(const Plan &pl, hipStream_t st, const TP *Uin, const TP *Vin, TP *Uout, TP *Vout,
                    float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
                    float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu = nullptr,
-                   float *Gv = nullptr)
+                   float *Gv = nullptr, int g_stride = 1)
 {
 #define MFCD_CASE(V, C)                                                                                              \
     if (pl.vec == V && pl.chunks == C)                                                                               \
         return launch_step<V, C, MODE, TP>(pl, st, Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, \
-                                           n, m, d, ac, loss_terms, Gu, Gv);
+                                           n, m, d, ac, loss_terms, Gu, Gv, g_stride);
     MFCD_CASE(4, 1) MFCD_CASE(4, 2) MFCD_CASE(4, 4) MFCD_CASE(4, 8)
     MFCD_CASE(1, 1) MFCD_CASE(1, 2) MFCD_CASE(1, 4) MFCD_CASE(1, 8)
 #undef MFCD_CASE
@@ -745,5 +781,112 @@ extern "C" int mfcd_adam_dense(float *U, float *V, float *mU, float *vU, float *
     dispatch_step<2>(pl, (hipStream_t)stream, U, V, U, V, mU, vU, mV, vV, nullptr, nullptr, 0, 0.0f, n, m, d, ac,
                      nullptr, const_cast<float *>(gradU), const_cast<float *>(gradV));
     MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Data-parallel training loop, native: per optimiser step one coefficient kernel over this rank's shard, ONE RCCL
+// all-gather (in place) of B {g, term} pairs per rank, one fused step kernel over the whole global batch — all
+// enqueued from here on one stream with no host synchronisation (replaces the per-step Python loop of mfcd/dist.py
+// for the "allgather" exchange; same protocol, same results).
+extern "C" int mfcd_dp_unique_id(void *id_out, size_t id_bytes)
+{
+    if (!id_out || id_bytes < sizeof(ncclUniqueId)) return MFCD_EINVAL;
+    const mfcd_detail::RcclApi &R = mfcd_detail::rccl();
+    if (!R.ok) return MFCD_ERCCL;
+    ncclUniqueId id;
+    if (R.GetUniqueId(&id) != ncclSuccess) return MFCD_ERCCL;
+    std::memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int mfcd_dp_comm_create(const void *id, size_t id_bytes, int rank, int world, void **comm_out)
+{
+    if (!id || id_bytes < sizeof(ncclUniqueId) || !comm_out || world < 1 || rank < 0 || rank >= world) return MFCD_EINVAL;
+    const mfcd_detail::RcclApi &R = mfcd_detail::rccl();
+    if (!R.ok) return MFCD_ERCCL;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    if (R.CommInitRank(&comm, world, uid, rank) != ncclSuccess) return MFCD_ERCCL;
+    *comm_out = (void *)comm;
+    return 0;
+}
+
+extern "C" int mfcd_dp_comm_destroy(void *comm)
+{
+    if (!comm) return 0;
+    const mfcd_detail::RcclApi &R = mfcd_detail::rccl();
+    if (!R.ok) return MFCD_ERCCL;
+    return R.CommDestroy((ncclComm_t)comm) == ncclSuccess ? 0 : MFCD_ERCCL;
+}
+
+extern "C" size_t mfcd_dp_workspace_bytes(int64_t N, int B, int world, int n, int m, int d)
+{
+    if (N < 0 || B <= 0 || world < 1 || n <= 0 || m <= 0 || d <= 0) return 0;
+    const int64_t Bg = (int64_t)B * world, nsteps = (N + Bg - 1) / Bg;
+    return kStatusBytes + align256(sizeof(float) * (size_t)n * d) + align256(sizeof(float) * (size_t)m * d) +
+           align256(sizeof(float2) * (size_t)(nsteps > 0 ? nsteps : 1) * (size_t)Bg);
+}
+
+extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                                   const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0,
+                                   int n, int m, int d, double lr, double beta1, double beta2, double eps,
+                                   double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
+                                   void *comm, void *stream)
+{
+    if (int rc = check_common(U, V, n, m, d)) return rc;
+    if (!mU || !vU || !mV || !vV || N < 0 || B <= 0 || world < 1 || rank < 0 || rank >= world || step0 < 0)
+        return MFCD_EINVAL;
+    if (N == 0) return 0;
+    if (!samples || !workspace) return MFCD_EINVAL;
+    if (workspace_bytes < mfcd_dp_workspace_bytes(N, B, world, n, m, d)) return MFCD_EWORKSPACE;
+    const mfcd_detail::RcclApi *R = nullptr;
+    if (comm) {
+        R = &mfcd_detail::rccl();
+        if (!R->ok) return MFCD_ERCCL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t Bg = (int64_t)B * world, nsteps = (N + Bg - 1) / Bg;
+    char *ws = (char *)workspace + kStatusBytes;
+    float *Ualt = (float *)ws;
+    ws += align256(sizeof(float) * (size_t)n * d);
+    float *Valt = (float *)ws;
+    ws += align256(sizeof(float) * (size_t)m * d);
+    float2 *xbuf = (float2 *)ws;   // [nsteps][world][B] pairs = global sample order inside a step
+    const void *ptrs[] = {U, V, mU, vU, mV, vV, Ualt, Valt};
+    const Plan pl = make_plan(ptrs, 8, n, m, d);
+    for (int64_t k = 0; k < nsteps; ++k) {
+        const int64_t lo = k * Bg, hi = (lo + Bg < N) ? lo + Bg : N;
+        const int nglob = (int)(hi - lo);          // divisor of the mean (structure.py:849): the GLOBAL batch
+        const bool even = (k & 1) == 0;
+        const float *Uc = even ? U : Ualt, *Vc = even ? V : Valt;
+        float2 *xk = xbuf + (size_t)k * Bg;
+        // ranks this process computes: its own; or, without a communicator, every rank in turn (replicas are
+        // bit-identical, so this reproduces the gathered buffer exactly: single-process rehearsal of any world size)
+        const int r0 = comm ? rank : 0, r1 = comm ? rank + 1 : world;
+        for (int r = r0; r < r1; ++r) {
+            const int64_t mylo = (lo + (int64_t)r * B < hi) ? lo + (int64_t)r * B : hi;
+            const int64_t myhi = (mylo + B < hi) ? mylo + B : hi;
+            hipLaunchKernelGGL(dp_coeff_kernel, dim3((B + 3) / 4), dim3(256), 0, st, Uc, Vc, samples + mylo,
+                               (int)(myhi - mylo), B, d, 1.0f / (float)nglob, xk + (size_t)r * B);
+        }
+        if (comm && world > 1) {
+            if (R->AllGather(xk + (size_t)rank * B, xk, (size_t)B * 2, ncclFloat, (ncclComm_t)comm, st) != ncclSuccess)
+                return MFCD_ERCCL;
+        }
+        const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step0 + k + 1);
+        dispatch_step<0, float>(pl, st, Uc, Vc, even ? Ualt : U, even ? Valt : V, mU, vU, mV, vV, samples + lo,
+                                (const float *)xk, nglob, 0.0f, n, m, d, ac, nullptr, nullptr, nullptr, 2);
+    }
+    MFCD_HIP_TRY(hipGetLastError());
+    if (nsteps & 1) {
+        MFCD_HIP_TRY(hipMemcpyAsync(U, Ualt, sizeof(float) * (size_t)n * d, hipMemcpyDeviceToDevice, st));
+        MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(float) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
+    }
+    if (loss_per_step) {
+        hipLaunchKernelGGL(dp_loss_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, xbuf, N, (int)Bg, loss_per_step);
+        MFCD_HIP_TRY(hipGetLastError());
+    }
     return 0;
 }

@@ -39,6 +39,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSlices = 256;  // row slices for the deterministic column-sum of U and V
 
+// a table of `rows` rows is cut into slices of >= 128 rows (at most kSlices of them)
+__host__ __device__ inline int slices_for(int rows) { return rows >= 128 * kSlices ? kSlices : (rows + 127) / 128; }
+
 // partial[slice][k] = sum over rows of the slice of T[row][k]  (f64), grid = (kSlices, 2 tables).
 // The 256 threads form G = 256/d row groups (1 when d >= 256): thread -> (group g, column k); a group walks every
 // G-th row of the slice with four loads in flight, the groups are combined through LDS in fixed order.
@@ -49,7 +52,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     const bool isV = blockIdx.y == 1;
     const float *T = isV ? V : U;
     const int rows = isV ? m : n;
-    const int per = (rows + kSlices - 1) / kSlices;
+    const int nsl = slices_for(rows);
+    if ((int)blockIdx.x >= nsl) return;
+    const int per = (rows + nsl - 1) / nsl;
     const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
     double *out = part + ((size_t)blockIdx.y * kSlices + blockIdx.x) * d;
     const int G = d >= 256 ? 1 : 256 / d;
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restr
     const int tab = blockIdx.y;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < d; k += gridDim.x * 256) {
         double acc = 0.0;
-        for (int s = 0; s < kSlices; ++s) acc += part[((size_t)tab * kSlices + s) * d + k];
+        const int nsl = slices_for(tab ? m : n);
+        for (int s = 0; s < nsl; ++s) acc += part[((size_t)tab * kSlices + s) * d + k];
         bar[(size_t)tab * d + k] = (float)(acc / (double)(tab ? m : n));
     }
 }

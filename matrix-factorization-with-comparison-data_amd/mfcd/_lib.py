@@ -31,6 +31,12 @@ SIGNATURES = {
     "mfcd_apply_step": (_i32, [_vp] * 8 + [_i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _sz, _vp]),
     "mfcd_dense_grad": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfcd_adam_dense": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp]),
+    "mfcd_dp_unique_id": (_i32, [_vp, _sz]),
+    "mfcd_dp_comm_create": (_i32, [_vp, _sz, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "mfcd_dp_comm_destroy": (_i32, [_vp]),
+    "mfcd_dp_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _i32]),
+    "mfcd_dp_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
+                            [_vp, _vp, _sz, _vp, _vp]),
     "mfcd_uvt_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mfcd_uvt_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_uvt_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -6,6 +6,12 @@ slice [r*B, (r+1)*B) of every global batch; the divisor of the mean loss is the 
 result equals the single-GPU run with batch_size = B*R up to summation order, and every rank ends each
 step with bit-identical replicas (they all apply the same gathered/reduced quantities in the same order).
 
+The product path is `NativeDP`: the whole per-step loop (coefficient kernel, ONE in-place ncclAllGather of the
+B {g, term} pairs per rank, fused step over the global batch) runs inside libmfcd_hip.so (mfcd_dp_train_steps),
+which binds RCCL at run time; Python only hands over pointers once per epoch.  `train_steps_dp` below is the same
+protocol spelled out step by step over torch.distributed (any backend): it is what the CPU tests drive with gloo
+and an oracle-backed compute object, and it also carries the north star's dense "allreduce" form.
+
 Two exact forms of the per-step exchange:
   "allreduce"  the north-star form: each rank scatters its samples' row gradients into a dense
                [(n+m), d] fp32 buffer, ONE all-reduce(sum) of that buffer, then dense Adam from it;
@@ -81,6 +87,69 @@ class HipCompute:
         self.b.advance(1)
 
 
+class NativeDP:
+    """Data-parallel optimiser steps through the native loop (include/mfcd.h: mfcd_dp_train_steps).
+
+    With a torch.distributed group, rank 0 draws an ncclUniqueId that is broadcast over that group, and every rank
+    creates its own RCCL communicator inside the library (on the current device).  Without a group (`world` given
+    explicitly, comm-less) the library computes every rank's shard in this process: the single-process rehearsal
+    the GPU tests use to check the sharding at world sizes a one-GPU box cannot host."""
+
+    ID_BYTES = 128
+
+    def __init__(self, binding, group=None, simulate_world=None):
+        import ctypes
+        self.b = binding
+        self.L = _lib.load()
+        U, V = binding.model.U.data, binding.model.V.data
+        self.n, self.d, self.m, self.dev = U.shape[0], U.shape[1], V.shape[0], U.device
+        self.comm = None
+        if simulate_world is not None:
+            self.rank, self.world = 0, int(simulate_world)
+        else:
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            uid = torch.zeros(self.ID_BYTES, dtype=torch.uint8)
+            if self.rank == 0:
+                buf = (ctypes.c_ubyte * self.ID_BYTES)()
+                _lib.check(self.L.mfcd_dp_unique_id(ctypes.cast(buf, ctypes.c_void_p), self.ID_BYTES))
+                uid = torch.tensor(list(buf), dtype=torch.uint8)
+            backend = dist.get_backend(group)
+            carrier = uid.to(self.dev) if backend == "nccl" else uid
+            dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            raw = bytes(carrier.cpu().tolist())
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(self.dev):
+                _lib.check(self.L.mfcd_dp_comm_create(raw, self.ID_BYTES, self.rank, self.world, ctypes.byref(handle)))
+            self.comm = handle
+        self.ws = None
+
+    def close(self):
+        if self.comm is not None:
+            torch.cuda.synchronize(self.dev)
+            _lib.check(self.L.mfcd_dp_comm_destroy(self.comm))
+            self.comm = None
+
+    def train_steps(self, stream, batch_local, loss_out=None):
+        """Consume `stream` (the GLOBAL sample order, identical on every rank) in global batches of
+        batch_local * world.  Returns the fp32 device tensor of global batch-mean losses.  No host sync."""
+        U, V, mU, vU, mV, vV = self.b.tensors()
+        N = stream.shape[0]
+        Bg = batch_local * self.world
+        nsteps = (N + Bg - 1) // Bg
+        if loss_out is None:
+            loss_out = torch.empty(max(nsteps, 1), dtype=torch.float32, device=self.dev)
+        need = self.L.mfcd_dp_workspace_bytes(N, batch_local, self.world, self.n, self.m, self.d)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(int(need), dtype=torch.uint8, device=self.dev)
+        lr, b1, b2, eps, wd = self.b.hyper()
+        _lib.check(self.L.mfcd_dp_train_steps(
+            _lib.ptr(U), _lib.ptr(V), _lib.ptr(mU), _lib.ptr(vU), _lib.ptr(mV), _lib.ptr(vV), _lib.ptr(stream), N,
+            batch_local, self.rank, self.world, self.b.step, self.n, self.m, self.d, lr, b1, b2, eps, wd,
+            _lib.ptr(loss_out), _lib.ptr(self.ws), self.ws.numel(), self.comm, _lib.stream_ptr(self.dev)))
+        self.b.advance(nsteps)
+        return loss_out[:nsteps]
+
+
 def shard_bounds(global_lo, global_hi, batch_local, rank):
     """Sample range of `rank` inside the global batch [global_lo, global_hi): contiguous slices of batch_local."""
     lo = min(global_hi, global_lo + rank * batch_local)
@@ -142,7 +211,7 @@ def broadcast_state(binding, src=0, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
-def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="allgather"):
+def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
     """bench.py's N>1 leg: weak scaling, per-rank batch cfg['B'], global batch B*world; returns the JSON dict."""
     import time
 
@@ -160,7 +229,8 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="allgather"):
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
     binding = engine.AdamBinding(model, opt)
     broadcast_state(binding)
-    compute = HipCompute(binding)
+    compute = HipCompute(binding) if mode != "native" else None
+    native = NativeDP(binding) if mode == "native" else None
     train = engine.SampleStore(tr, cfg["n"], cfg["m"], dev)
     val = engine.SampleStore(va, cfg["n"], cfg["m"], dev)
     gen = torch.Generator().manual_seed(seed + 1)           # same permutations on every rank
@@ -176,7 +246,10 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="allgather"):
                 state["stream"], state["pos"] = train.ordered(torch.randperm(train.N, generator=gen)), 0
             take = min(steps_per_epoch - state["pos"], nsteps)
             lo, hi = state["pos"] * Bg, min(train.N, (state["pos"] + take) * Bg)
-            train_steps_dp(compute, state["stream"][lo:hi], B, mode=mode)
+            if native is not None:
+                native.train_steps(state["stream"][lo:hi], B)
+            else:
+                train_steps_dp(compute, state["stream"][lo:hi], B, mode=mode)
             consumed += hi - lo
             state["pos"] += take
             nsteps -= take
@@ -203,6 +276,11 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="allgather"):
     dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
     in_sync = bool(torch.equal(lo_, hi_))
+    if native is not None:
+        native.close()
+    what = {"native": "native loop in libmfcd_hip.so: one in-place RCCL all-gather of 64 {g, term} pairs per rank per "
+                      "optimiser step", "allgather": "torch.distributed all-gather per optimiser step",
+            "allreduce": "dense fp32 gradient all-reduce per optimiser step"}[mode]
     abytes = bench_mod.algorithmic_bytes_per_step(dict(cfg, B=Bg))
     return {
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
@@ -210,7 +288,7 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="allgather"):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C2: n=m=4096 d=64 p=0.01 random triplets, per-GPU batch 64, Adam lr=1e-3 wd=1e-5, "
                                "validation pass per epoch", "global_batch": Bg, "train_samples": train.N,
-                   "parallelism": f"dp{world} ({mode}: one RCCL collective per optimiser step)",
+                   "parallelism": f"dp{world} ({what})",
                    "replicas_in_sync": in_sync},
         "roofline": {"bound": "hbm", "achieved": round(abytes / (dt / steps) / 1e9, 1), "peak": bench_mod.HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(abytes / (dt / steps) / 1e9 / bench_mod.HBM_PEAK_GBS, 4),

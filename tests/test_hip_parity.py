@@ -421,6 +421,68 @@ def test_data_parallel_hip_backend_single_rank(dev, mode):
     np.testing.assert_allclose(model.V.data.cpu().numpy(), ref_V, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("world,N", [(1, 64 * 9 + 5), (2, 64 * 2 * 7 + 70), (3, 64 * 3 * 5 + 130), (8, 64 * 8 * 3 + 1)])
+def test_native_dp_loop_single_process_rehearsal(dev, world, N):
+    """mfcd_dp_train_steps without a communicator computes every rank's shard in this process (replicas are
+    identical, so that IS the gathered buffer): shard bounds, padding of short / empty shards and the global divisor
+    must make the run bit-identical to the fused streaming step with batch_size = 64 * world."""
+    from mfcd import dist as mdist, engine
+    n, m, d, B = 300, 260, 32, 64
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=100 + world)
+    st = _records(u, i, j, z, n, m, dev)
+    engine.set_train_path("streaming")
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        ref_loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B * world).cpu().numpy()
+        ref_U, ref_V = model.U.data.cpu().numpy(), model.V.data.cpu().numpy()
+    finally:
+        engine.set_train_path("auto")
+    model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+    bind = engine.AdamBinding(model, opt)
+    losses = mdist.NativeDP(bind, simulate_world=world).train_steps(st.dev, B).cpu().numpy()
+    assert bind.step == len(ref_loss) == (N + B * world - 1) // (B * world)
+    np.testing.assert_allclose(losses, ref_loss, rtol=1e-6, atol=1e-7)      # same terms, different summation tree
+    np.testing.assert_array_equal(model.U.data.cpu().numpy(), ref_U)
+    np.testing.assert_array_equal(model.V.data.cpu().numpy(), ref_V)
+
+
+def test_native_dp_loop_over_rccl_single_rank(dev):
+    """The native loop with a real RCCL communicator (created inside libmfcd_hip.so from an ncclUniqueId carried over
+    torch.distributed) on a one-rank group reproduces the fused streaming step bit for bit."""
+    import os
+    import torch.distributed as dist
+    from mfcd import dist as mdist, engine
+    n, m, d, N, B = 700, 500, 64, 64 * 30 + 21, 64
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=21)
+    st = _records(u, i, j, z, n, m, dev)
+    engine.set_train_path("streaming")
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        ref_loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).cpu().numpy()
+        ref_U, ref_V = model.U.data.cpu().numpy(), model.V.data.cpu().numpy()
+    finally:
+        engine.set_train_path("auto")
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        bind = engine.AdamBinding(model, opt)
+        ndp = mdist.NativeDP(bind)
+        assert ndp.comm is not None and ndp.world == 1
+        losses = ndp.train_steps(st.dev, B).cpu().numpy()
+        ndp.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    np.testing.assert_allclose(losses, ref_loss, rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(model.U.data.cpu().numpy(), ref_U)
+    np.testing.assert_array_equal(model.V.data.cpu().numpy(), ref_V)
+
+
 def _describe(o):
     if isinstance(o, dict):
         return {"type": "dict", "items": {k: _describe(v) for k, v in o.items()}}
