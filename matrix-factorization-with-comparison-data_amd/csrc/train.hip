@@ -871,7 +871,7 @@ extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, flo
             hipLaunchKernelGGL(dp_coeff_kernel, dim3((B + 3) / 4), dim3(256), 0, st, Uc, Vc, samples + mylo,
                                (int)(myhi - mylo), B, d, 1.0f / (float)nglob, xk + (size_t)r * B);
         }
-        if (comm && world > 1) {
+        if (comm) {   // also on a one-rank communicator: the call path is the same at every world size
             if (R->AllGather(xk + (size_t)rank * B, xk, (size_t)B * 2, ncclFloat, (ncclComm_t)comm, st) != ncclSuccess)
                 return MFCD_ERCCL;
         }
