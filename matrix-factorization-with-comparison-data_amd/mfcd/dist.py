@@ -229,8 +229,17 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
     binding = engine.AdamBinding(model, opt)
     broadcast_state(binding)
-    compute = HipCompute(binding) if mode != "native" else None
-    native = NativeDP(binding) if mode == "native" else None
+    native = None
+    if mode == "native":
+        # RCCL not loadable inside the library is the same on every rank (same image, same process layout): then the
+        # per-step torch.distributed loop over the same HIP kernels takes over, and the JSON line says so
+        try:
+            native = NativeDP(binding)
+        except _lib.MfcdError as e:
+            if "RCCL" not in str(e):
+                raise
+            mode = "allgather"
+    compute = HipCompute(binding) if native is None else None
     train = engine.SampleStore(tr, cfg["n"], cfg["m"], dev)
     val = engine.SampleStore(va, cfg["n"], cfg["m"], dev)
     gen = torch.Generator().manual_seed(seed + 1)           # same permutations on every rank
