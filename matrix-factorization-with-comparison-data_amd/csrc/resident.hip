@@ -78,7 +78,7 @@ ResidentPlan plan_resident(int n, int m, int d, int num_cus)
         const int Q = kQ[qi];
         if ((64 * Q) % d != 0 || (forced_q && Q != forced_q)) continue;
         const int64_t nw = (T + 64 * (int64_t)Q - 1) / (64 * Q);
-        if (nw <= (int64_t)num_cus * (Q <= 2 ? wpc : 8)) {
+        if (nw <= (int64_t)num_cus * (Q <= 2 ? wpc : 8) && nw <= kResidentMaxWaves) {
             pl.ok = true;
             pl.Q = Q;
             pl.NW = (int)nw;
@@ -89,10 +89,29 @@ ResidentPlan plan_resident(int n, int m, int d, int num_cus)
     return pl;
 }
 
+// touch[w][k >> 5] bit (k & 31) = batch k holds a sample with a row of wave w (rows_per_wave consecutive global rows
+// per wave, V rows offset by n).  One thread per sample; the strings are zero-filled before.
+__global__ __launch_bounds__(256) void touch_build_kernel(const mfcd_sample *__restrict__ samples, int64_t N, int B,
+                                                          int n, int rows_per_wave, int KW, unsigned *__restrict__ touch)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= N) return;
+    const mfcd_sample s = samples[t];
+    const int k = (int)(t / B);
+    const unsigned bit = 1u << (k & 31);
+    const int word = k >> 5;
+    const int wu = s.u / rows_per_wave, wi = (s.i + n) / rows_per_wave, wj = (s.j + n) / rows_per_wave;
+    atomicOr(touch + (size_t)wu * KW + word, bit);
+    atomicOr(touch + (size_t)wi * KW + word, bit);
+    if (wj != wi) atomicOr(touch + (size_t)wj * KW + word, bit);
+}
+
+int resident_touch_words(int K) { return (K + 31) / 32 + 3; }
+
 int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
                           const mfcd_sample *samples, int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev,
                           const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status,
-                          unsigned long long *dbg, int K, hipStream_t st)
+                          unsigned long long *dbg, unsigned *touch, int K, hipStream_t st)
 {
     ResidentArgs a;
     a.dbg = dbg;
@@ -105,6 +124,14 @@ int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
     // tiny tables: a batch touches so large a share of the rows that nearly every row recurs inside the window
     // and each publish takes the deferred (slow) path; publishing right before use is faster there
     if (!la && (int64_t)(n + m) < (int64_t)96 * B) a.lookahead = 0;
+    a.touch = touch;
+    a.KW = resident_touch_words(K);
+    if (a.lookahead > 0 && B <= 64) {   // the look-ahead form reads the per-wave touch strings
+        if (!touch) return MFCD_EINVAL;
+        MFCD_HIP_TRY(hipMemsetAsync(touch, 0, sizeof(unsigned) * (size_t)pl.NW * a.KW, st));
+        hipLaunchKernelGGL(touch_build_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, samples, N, B, n,
+                           64 * pl.Q / d, a.KW, touch);
+    }
     const char *fm = getenv("MFCD_RESIDENT_MATH");   // experiment knob: "ieee" / "fast" overrides mfcd_set_resident_math
     a.fast_math = fm ? (fm[0] == 'f') : g_resident_math;
     const char *lp = getenv("MFCD_RESIDENT_LDS_PAD");   // experiment knob (bytes)

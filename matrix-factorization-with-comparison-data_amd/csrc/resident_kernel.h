@@ -51,6 +51,8 @@ struct ResidentArgs {
     float *loss_terms;       // [N]
     int *status;             // 0 = ok, 1 = a bounded spin expired
     u64 *dbg;                // [NW][8] cycle accounting (diagnostic build only)
+    const unsigned *touch;   // [NW][KW] bit s of wave w's string = "batch s touches a row of wave w" (look-ahead form)
+    int KW;                  // dwords per wave in `touch` (covers K + 64 steps; bits past K are zero)
     int64_t N;
     int B, n, m, K, NW;
     int lookahead;           // 0: publish right before use (any B); >0: look-ahead form (B <= 64)
@@ -269,11 +271,6 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             s.j = valid ? s.j : -0x40000000;
             return s;
         };
-        auto any_mask = [&](const mfcd_sample &s) {                // inert lanes hold -2^30: never in range
-            const unsigned du_ = (unsigned)(s.u - ulo), di_ = (unsigned)(s.i - vlo), dj_ = (unsigned)(s.j - vlo);
-            const unsigned dv_ = di_ < dj_ ? di_ : dj_;
-            return (u64)__ballot((du_ < (unsigned)ucnt) | (dv_ < (unsigned)vcnt));
-        };
         auto role_masks = [&](const mfcd_sample &s) {
             Masks M;
             M.mu = __ballot(ownsU && (unsigned)(s.u - ulo) < (unsigned)ucnt);
@@ -293,19 +290,17 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             return __ballot(s.u == R || s.i + a.n == R || s.j + a.n == R) != 0ull;
         };
 
-        u64 anyw[W + 1];          // anyw[b] = any-mask of batch j+b, j = the step just finished
-        anyw[0] = 0ull;           // before step 0: "batch -1" is empty
-#pragma unroll
-        for (int b2 = 1; b2 <= W; ++b2) anyw[b2] = any_mask(load_rec(b2 - 1));
-        mfcd_sample rec_new = load_rec(W);                         // batch W, scanned at k = 0
+        // Which batches touch a row of mine is known before the launch (touch_build_kernel: one pass over the call's
+        // samples).  `win` is a sliding window over my bit string: bit b <-> batch j + b, j = the step just finished;
+        // it replaces a per-step record load + range test + ballot per wave (every wave scanning every batch).
+        const unsigned *const tw = a.touch + (size_t)__builtin_amdgcn_readfirstlane(gw) * a.KW;
+        u64 win = (u64)tw[0] << 1;   // j = -1: "batch -1" is empty
+        int fill = 33, widx = 1;     // bits 0 .. fill-1 of win are valid; the next dword of the string goes to bit `fill`
 
         // publish, from the state after step j, every (k, R) whose turn it is (see the template comment)
         auto publish_phase = [&](int j, bool first) {
-            u64 cand = anyw[W];
-            if (first || anyw[0] != 0ull) {
-#pragma unroll
-                for (int b2 = 1; b2 < W; ++b2) cand |= anyw[b2];
-            }
+            u64 cand = win & (1ull << W);
+            if (first || (win & 1ull)) cand |= win & ((1ull << W) - 2ull);   // bits 1 .. W-1
             if (cand == 0ull) return;                              // the common case
             // slow path: bring the whole window's records in with ONE burst of independent loads
             mfcd_sample wrec[W + 1];
@@ -314,8 +309,8 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #pragma unroll
             for (int kk = 1; kk <= W; ++kk) {
                 const int k = j + kk;
-                if (anyw[kk] == 0ull || k >= a.K) continue;
-                if (kk < W && !first && anyw[0] == 0ull) continue; // none of my rows was touched by batch j
+                if (!((win >> kk) & 1ull) || k >= a.K) continue;
+                if (kk < W && !first && !(win & 1ull)) continue;   // none of my rows was touched by batch j
                 const mfcd_sample rk = wrec[kk];
                 const Masks Mk = role_masks(rk);
                 u64 pm = Mk.mu | Mk.mi | Mk.mj;
@@ -373,16 +368,19 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         StepScalars sc_cur = a.sc[0];
         const StepScalars *sc_ptr = a.sc + 1;      // running pointer: the table holds K+1 entries (host pads one)
         for (int k = 0; k < a.K; ++k) {
-            // slide the window: anyw[0] becomes batch k; scan batch k+W (record prefetched during the last step)
-#pragma unroll
-            for (int b2 = 0; b2 < W; ++b2) anyw[b2] = anyw[b2 + 1];
-            anyw[W] = any_mask(rec_new);
-            rec_new = load_rec(k + W + 1);
+            // slide the window: bit 0 becomes batch k
+            win >>= 1;
+            --fill;
+            if (fill < 16) {
+                win |= (u64)tw[widx] << fill;
+                ++widx;
+                fill += 32;
+            }
             const StepScalars sc_next = *sc_ptr++;
 
 #pragma unroll
             for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
-            if (anyw[0] != 0ull) {
+            if (win & 1ull) {
                 const mfcd_sample rk = load_rec(k);
                 const Masks M0 = role_masks(rk);
                 const int64_t pos0 = (int64_t)k * a.B;

@@ -413,7 +413,7 @@ int device_cus()
 }
 
 struct ResidentLayout {
-    size_t dbg_off, cold_off, sc_off, terms_off, mailbox_off, mailbox_bytes, total;
+    size_t dbg_off, cold_off, sc_off, terms_off, touch_off, mailbox_off, mailbox_bytes, total;
 };
 
 constexpr size_t kColdBytes = 64;   // ResidentCold: six table pointers + padding, directly in front of the scalar table
@@ -432,6 +432,9 @@ ResidentLayout resident_layout(int64_t N, int B, int d)
     off += align256(kColdBytes + sizeof(StepScalars) * (size_t)(K + 1));   // one pad entry: the kernel reads step k+1
     L.terms_off = off;
     off += align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    L.touch_off = off;   // per-wave touch strings of the look-ahead form (resident.hip)
+    off += align256(sizeof(unsigned) * (size_t)mfcd_detail::kResidentMaxWaves *
+                    (size_t)mfcd_detail::resident_touch_words((int)(K < 0x7fffff00 ? K : 0x7fffff00)));
     L.mailbox_off = off;
     L.mailbox_bytes = sizeof(unsigned long long) * (size_t)N * 3 * (size_t)d;
     off += align256(L.mailbox_bytes > 0 ? L.mailbox_bytes : 1);
@@ -608,8 +611,8 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
         }
         if (int rc = mfcd_detail::launch_resident_steps(rp, base + L.cold_off, samples, N, B, n, m, d, sc_dev,
                                                        adam_static(beta1, beta2, eps, weight_decay), mailbox, terms_r,
-                                                       status, (unsigned long long *)(base + L.dbg_off), (int)nsteps,
-                                                       st))
+                                                       status, (unsigned long long *)(base + L.dbg_off),
+                                                       (unsigned *)(base + L.touch_off), (int)nsteps, st))
             return rc;
         if (timing_us) MFCD_HIP_TRY(hipEventRecord(e1, st));
         if (loss_per_step) {
