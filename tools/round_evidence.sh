@@ -18,6 +18,9 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/prof_bench -- python3 $R/bench.py --no-cpu-baseline > $E/bench_c2_under_rocprof.json 2>/dev/null
 MFCD_SKIP_TORCH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $E/prof_uvt -- python3 $R/tools/bench_uvt.py C2 C3 C5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/prof_dp -- python3 $R/bench.py --dp-mode native --no-cpu-baseline --steps 2098 --warmup 1049 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $E/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2098 --warmup 1049 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $E/pmc_write -- python3 $R/bench.py --no-cpu-baseline --steps 2098 --warmup 1049 > /dev/null 2>&1
+python3 $R/tools/pmc_traffic.py $E/pmc_fetch $E/pmc_write $E/pmc_traffic.json | tail -12
 find $E -name "*kernel_stats.csv" | head
 # keep only the stats summaries (the traces are large)
 find $E -name "*kernel_trace.csv" -size +8M -delete || true
