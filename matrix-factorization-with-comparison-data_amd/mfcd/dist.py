@@ -102,6 +102,8 @@ class NativeDP:
         self.b = binding
         self.L = _lib.load()
         U, V = binding.model.U.data, binding.model.V.data
+        if U.dtype != torch.float32:
+            raise NotImplementedError("the data-parallel loop takes fp32 factors (bf16 factor storage is single-GPU)")
         self.n, self.d, self.m, self.dev = U.shape[0], U.shape[1], V.shape[0], U.device
         self.comm = None
         if simulate_world is not None:
