@@ -89,18 +89,21 @@ ResidentPlan plan_resident(int n, int m, int d, int num_cus)
     return pl;
 }
 
-// touch[w][k >> 5] bit (k & 31) = batch k holds a sample with a row of wave w (rows_per_wave consecutive global rows
-// per wave, V rows offset by n).  One thread per sample; the strings are zero-filled before.
+// touch[w][k >> 5] bit (k & 31) = batch k holds a sample with a row of wave w (rows_per_wave consecutive VIRTUAL rows
+// per wave: RowMap in resident_kernel.h).  One thread per sample; the strings are zero-filled before.
 __global__ __launch_bounds__(256) void touch_build_kernel(const mfcd_sample *__restrict__ samples, int64_t N, int B,
-                                                          int n, int rows_per_wave, int KW, unsigned *__restrict__ touch)
+                                                          int n, int m, int rows_per_wave, int KW,
+                                                          unsigned *__restrict__ touch)
 {
+    const RowMap rmap = make_row_map(n, m);
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= N) return;
     const mfcd_sample s = samples[t];
     const int k = (int)(t / B);
     const unsigned bit = 1u << (k & 31);
     const int word = k >> 5;
-    const int wu = s.u / rows_per_wave, wi = (s.i + n) / rows_per_wave, wj = (s.j + n) / rows_per_wave;
+    const int wu = rmap.vrow_u(s.u) / rows_per_wave, wi = rmap.vrow_v(s.i) / rows_per_wave,
+              wj = rmap.vrow_v(s.j) / rows_per_wave;
     atomicOr(touch + (size_t)wu * KW + word, bit);
     atomicOr(touch + (size_t)wi * KW + word, bit);
     if (wj != wi) atomicOr(touch + (size_t)wj * KW + word, bit);
@@ -130,7 +133,7 @@ int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
         if (!touch) return MFCD_EINVAL;
         MFCD_HIP_TRY(hipMemsetAsync(touch, 0, sizeof(unsigned) * (size_t)pl.NW * a.KW, st));
         hipLaunchKernelGGL(touch_build_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, samples, N, B, n,
-                           64 * pl.Q / d, a.KW, touch);
+                           m, 64 * pl.Q / d, a.KW, touch);
     }
     const char *fm = getenv("MFCD_RESIDENT_MATH");   // experiment knob: "ieee" / "fast" overrides mfcd_set_resident_math
     a.fast_math = fm ? (fm[0] == 'f') : g_resident_math;
