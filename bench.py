@@ -86,6 +86,7 @@ class Runner:
         self.gen = torch.Generator().manual_seed(seed + 1)
         self.steps_per_epoch = (self.train.N + cfg["B"] - 1) // cfg["B"]
         self.stream, self.pos = None, 0
+        self.pre = engine.StreamPrefetch(dev)   # next epoch's record stream is built under the running step kernel
         self.train_events = []  # (start, stop, launches) around each fused-step call in the timed region
 
     def run(self, steps, record=False):
@@ -94,8 +95,9 @@ class Runner:
         B, consumed = self.cfg["B"], 0
         while steps > 0:
             if self.stream is None:
-                order = torch.randperm(self.train.N, generator=self.gen)
-                self.stream, self.pos = self.train.ordered(order), 0
+                if self.pre.pending is None:
+                    self.pre.start(self.train, torch.randperm(self.train.N, generator=self.gen))
+                self.stream, self.pos = self.pre.take(), 0
             left = self.steps_per_epoch - self.pos
             take = min(left, steps)
             lo, hi = self.pos * B, min(self.train.N, (self.pos + take) * B)
@@ -109,6 +111,9 @@ class Runner:
             consumed += hi - lo
             self.pos += take
             steps -= take
+            if self.pos == self.steps_per_epoch and self.pre.pending is None:
+                # the epoch's last steps are enqueued: start building the next epoch's stream underneath them
+                self.pre.start(self.train, torch.randperm(self.train.N, generator=self.gen))
             if self.pos == self.steps_per_epoch:  # structure.py:858-868
                 self.engine.eval_batches(self.model.U.data, self.model.V.data, self.val.dev, B)
                 self.stream = None
