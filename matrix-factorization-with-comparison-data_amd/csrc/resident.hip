@@ -89,37 +89,75 @@ ResidentPlan plan_resident(int n, int m, int d, int num_cus)
     return pl;
 }
 
-// touch[w][k >> 5] bit (k & 31) = batch k holds a sample with a row of wave w (rows_per_wave consecutive VIRTUAL rows
-// per wave: RowMap in resident_kernel.h).  One thread per sample; the strings are zero-filled before.
-__global__ __launch_bounds__(256) void touch_build_kernel(const mfcd_sample *__restrict__ samples, int64_t N, int B,
-                                                          int n, int m, int rows_per_wave, int KW,
-                                                          unsigned *__restrict__ touch)
+// ---- row order ----
+// The kernel only sees VIRTUAL row ids: the order is written once per launch as two tables (vrow: table row -> virtual
+// row, inv: the inverse), the samples are translated with them, and the slice load / store goes through `inv`.  The
+// order itself is the static interleave of RowMap (resident_kernel.h).  A per-launch order rebuilt from the launch's own
+// touch counts (rows sorted by count, dealt to the waves in snake order: 49 +- 2 hits per wave instead of 49 +- 7) was
+// measured and dropped: the kernel ran within 1 % of the static order and the sort cost 63 us per launch.
+__global__ __launch_bounds__(256) void resident_order_kernel(int n, int m, int *__restrict__ vrow, int *__restrict__ inv)
 {
-    const RowMap rmap = make_row_map(n, m);
+    const RowMap rm = make_row_map(n, m);
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n + m) return;
+    const bool item = r >= n;
+    const int vr = item ? rm.vrow_v(r - n) : rm.vrow_u(r);
+    vrow[r] = vr;
+    inv[vr] = (item ? (int)0x80000000 : 0) | (item ? r - n : r);
+}
+
+// Translates the call's samples to virtual row ids (xs) and builds the per-wave touch strings:
+// touch[w][k >> 5] bit (k & 31) = batch k holds a sample with a row of wave w (rows_per_wave consecutive virtual rows
+// per wave).  One thread per sample; the strings are zero-filled before.
+__global__ __launch_bounds__(256) void resident_translate_kernel(const mfcd_sample *__restrict__ samples, int64_t N,
+                                                                 int B, int n, const int *__restrict__ vrow,
+                                                                 int rows_per_wave, int KW, int want_touch,
+                                                                 mfcd_sample *__restrict__ xs,
+                                                                 unsigned *__restrict__ touch)
+{
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= N) return;
-    const mfcd_sample s = samples[t];
+    mfcd_sample s = samples[t];
+    s.u = vrow[s.u];
+    s.i = vrow[n + s.i];
+    s.j = vrow[n + s.j];
+    xs[t] = s;
+    if (!want_touch) return;
     const int k = (int)(t / B);
     const unsigned bit = 1u << (k & 31);
     const int word = k >> 5;
-    const int wu = rmap.vrow_u(s.u) / rows_per_wave, wi = rmap.vrow_v(s.i) / rows_per_wave,
-              wj = rmap.vrow_v(s.j) / rows_per_wave;
+    const int wu = s.u / rows_per_wave, wi = s.i / rows_per_wave, wj = s.j / rows_per_wave;
     atomicOr(touch + (size_t)wu * KW + word, bit);
-    atomicOr(touch + (size_t)wi * KW + word, bit);
-    if (wj != wi) atomicOr(touch + (size_t)wj * KW + word, bit);
+    if (wi != wu) atomicOr(touch + (size_t)wi * KW + word, bit);
+    if (wj != wi && wj != wu) atomicOr(touch + (size_t)wj * KW + word, bit);
 }
 
 int resident_touch_words(int K) { return (K + 31) / 32 + 3; }
 
+size_t resident_aux_bytes(int64_t N, int n, int m, int K)
+{
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return al(sizeof(int) * (size_t)(n + m)) * 2 + al(sizeof(mfcd_sample) * (size_t)(N > 0 ? N : 1)) +
+           al(sizeof(unsigned) * (size_t)kResidentMaxWaves * (size_t)resident_touch_words(K));
+}
+
 int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
                           const mfcd_sample *samples, int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev,
                           const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status,
-                          unsigned long long *dbg, unsigned *touch, int K, hipStream_t st)
+                          unsigned long long *dbg, void *aux, int K, hipStream_t st)
 {
+    if (!aux) return MFCD_EINVAL;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    char *ap = (char *)aux;                     // carve-up of the aux region (resident_aux_bytes)
+    int *vrow = (int *)ap; ap += al(sizeof(int) * (size_t)(n + m));
+    int *inv = (int *)ap;  ap += al(sizeof(int) * (size_t)(n + m));
+    mfcd_sample *xs = (mfcd_sample *)ap; ap += al(sizeof(mfcd_sample) * (size_t)(N > 0 ? N : 1));
+    unsigned *touch = (unsigned *)ap;
+
     ResidentArgs a;
     a.dbg = dbg;
     a.cold = (const ResidentCold *)cold_dev;
-    a.samples = samples; a.sc = sc_dev; a.mailbox = mailbox; a.loss_terms = loss_terms; a.status = status;
+    a.samples = xs; a.sc = sc_dev; a.mailbox = mailbox; a.loss_terms = loss_terms; a.status = status;
     a.N = N; a.B = B; a.n = n; a.m = m; a.K = K; a.NW = pl.NW; a.ac = ac;
     const char *la = getenv("MFCD_RESIDENT_LOOKAHEAD");  // tuning/test override: 0 disables look-ahead publishing
     a.lookahead = la ? atoi(la) : 4;
@@ -127,14 +165,17 @@ int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
     // tiny tables: a batch touches so large a share of the rows that nearly every row recurs inside the window
     // and each publish takes the deferred (slow) path; publishing right before use is faster there
     if (!la && (int64_t)(n + m) < (int64_t)96 * B) a.lookahead = 0;
+    a.inv = inv;
     a.touch = touch;
     a.KW = resident_touch_words(K);
-    if (a.lookahead > 0 && B <= 64) {   // the look-ahead form reads the per-wave touch strings
-        if (!touch) return MFCD_EINVAL;
-        MFCD_HIP_TRY(hipMemsetAsync(touch, 0, sizeof(unsigned) * (size_t)pl.NW * a.KW, st));
-        hipLaunchKernelGGL(touch_build_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, samples, N, B, n,
-                           m, 64 * pl.Q / d, a.KW, touch);
-    }
+    // row order tables, translated samples, touch strings
+    const int rpw = 64 * pl.Q / d;
+    const unsigned sblocks = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(resident_order_kernel, dim3((unsigned)((n + m + 255) / 256)), dim3(256), 0, st, n, m, vrow, inv);
+    const int want_touch = a.lookahead > 0 && B <= 64;   // the look-ahead form reads the per-wave touch strings
+    if (want_touch) MFCD_HIP_TRY(hipMemsetAsync(touch, 0, sizeof(unsigned) * (size_t)pl.NW * a.KW, st));
+    hipLaunchKernelGGL(resident_translate_kernel, dim3(sblocks), dim3(256), 0, st, samples, N, B, n, vrow, rpw, a.KW,
+                       want_touch, xs, touch);
     const char *fm = getenv("MFCD_RESIDENT_MATH");   // experiment knob: "ieee" / "fast" overrides mfcd_set_resident_math
     a.fast_math = fm ? (fm[0] == 'f') : g_resident_math;
     const char *lp = getenv("MFCD_RESIDENT_LDS_PAD");   // experiment knob (bytes)

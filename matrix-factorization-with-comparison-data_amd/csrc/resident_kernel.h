@@ -29,7 +29,10 @@ __device__ __forceinline__ void store_granule(u64 *p, unsigned tag, float v)
 // the hits of the others and set the pace (measured: the same state size split 2731 users / 5461 items, where all rows
 // are touched equally often, ran 12 % faster than 4096 / 4096).  The virtual order therefore INTERLEAVES the two tables
 // over their common length c = min(n, m): user r -> 2r, item r -> 2r + 1 (r < c); the rest of the longer table follows.
-// A wave's slice is still one contiguous range of user ids plus one contiguous range of item ids.
+// This static order is the FALLBACK; when the table is small enough the order is rebuilt for every launch from the
+// launch's own touch counts (resident.hip: resident_order_kernel) so that every wave carries the same number of hits.
+// Either way the kernel only sees virtual row ids: the samples are translated once per launch, and the slice load /
+// store goes through the inverse table.
 struct RowMap {
     int n, m, c;   // c = min(n, m)
     __host__ __device__ int vrow_u(int u) const { return u < c ? 2 * u : 2 * c + (u - c); }
@@ -77,12 +80,13 @@ struct ResidentCold {
 
 struct ResidentArgs {
     const ResidentCold *cold;
-    const mfcd_sample *samples;
+    const mfcd_sample *samples;   // the call's samples with u, i, j already translated to VIRTUAL row ids
     const StepScalars *sc;   // [K]
     u64 *mailbox;            // [N][3][D] granules, zero-filled before the launch
     float *loss_terms;       // [N]
     int *status;             // 0 = ok, 1 = a bounded spin expired
     u64 *dbg;                // [NW][8] cycle accounting (diagnostic build only)
+    const int *inv;          // [n+m] virtual row -> (item ? 0x80000000 : 0) | row inside U / V   (resident_order_kernel)
     const unsigned *touch;   // [NW][KW] bit s of wave w's string = "batch s touches a row of wave w" (look-ahead form)
     int KW;                  // dwords per wave in `touch` (covers K + 64 steps; bits past K are zero)
     int64_t N;
@@ -127,16 +131,15 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (gw >= a.NW) return;  // whole wave
 
-    const RowMap rmap = make_row_map(a.n, a.m);
     const int64_t T = (int64_t)(a.n + a.m) * D;
     const int64_t ebase = (int64_t)gw * EW;
     const int Rlo = (int)(ebase / D);
     const int64_t eend = (ebase + EW < T) ? ebase + EW : T;
-    const int Rhi = (int)(eend / D);  // my rows are VIRTUAL row ids [Rlo, Rhi) (RowMap: users and items interleaved)
+    const int Rhi = (int)(eend / D);  // my rows are VIRTUAL row ids [Rlo, Rhi)
     const int lcol = lane & (D - 1);  // column of my lane when D < 64
-    // element e of the virtual table -> address offset inside U or V
-    auto elem_is_item = [&](int64_t e) { return rmap.is_item((int)(e / D)); };
-    auto elem_offset = [&](int64_t e) { return (int64_t)rmap.table_row((int)(e / D)) * D + (e % D); };
+    // element e of the virtual table -> table and address offset inside U or V (kernel start and end only)
+    auto elem_is_item = [&](int64_t e) { return a.inv[e / D] < 0; };
+    auto elem_offset = [&](int64_t e) { return (int64_t)(a.inv[e / D] & 0x7fffffff) * D + (e % D); };
 
     // ---- load my slice of the state into registers ----
     float p[Q], m1[Q], m2[Q], gr[Q];
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
     };
     auto scan = [&](const mfcd_sample &s, int Bk, int base) {
         const bool valid = base + lane < Bk;
-        const int ru = rmap.vrow_u(s.u), ri = rmap.vrow_v(s.i), rj = rmap.vrow_v(s.j);
+        const int ru = s.u, ri = s.i, rj = s.j;   // virtual ids
         Masks M;
         M.mu = __ballot(valid && ru >= Rlo && ru < Rhi);
         M.mi = __ballot(valid && ri >= Rlo && ri < Rhi);
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
     // `hs` is the sample itself (wave-uniform), `M`/`tl` say which of its rows are mine.
     auto process_hit = [&](const mfcd_sample &hs, const Masks &M, int tl, int64_t pos, unsigned tag,
                            float inv_batch) -> bool {
-        const int rows[3] = {rmap.vrow_u(hs.u), rmap.vrow_v(hs.i), rmap.vrow_v(hs.j)};
+        const int rows[3] = {hs.u, hs.i, hs.j};
         const bool own[3] = {(bool)((M.mu >> tl) & 1ull), (bool)((M.mi >> tl) & 1ull), (bool)((M.mj >> tl) & 1ull)};
         const float zz = hs.z;
         const u64 *slot = a.mailbox + pos * 3 * D;
@@ -290,11 +293,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         // records themselves are re-derived from a reload only when such a sample exists.
         constexpr int W = LOOK;
         const int N32 = (int)a.N;                                  // host guarantees N + 64*(W+2) < 2^31
-        // my user rows [ulo, ulo+ucnt) and item rows [vlo, vlo+vcnt) (ids inside U / V); a count of 0 makes the unsigned
-        // range test below fail for every id, so the scan needs no branch on what kind of rows I own
-        const int ulo = rmap.users_below(Rlo), ucnt = rmap.users_below(Rhi) - ulo;
-        const int vlo = rmap.items_below(Rlo), vcnt = rmap.items_below(Rhi) - vlo;
-        const bool ownsU = ucnt > 0, ownsV = vcnt > 0;
+        const unsigned rcnt = (unsigned)(Rhi - Rlo);   // my rows: virtual ids [Rlo, Rlo + rcnt)
         // this lane's record of batch `step`: branch-free (clamped address, then inert ids for lanes past the batch
         // or past the stream), 32-bit byte offset from a scalar base
         const char *const sbase = (const char *)a.samples;
@@ -310,9 +309,9 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         };
         auto role_masks = [&](const mfcd_sample &s) {
             Masks M;
-            M.mu = __ballot(ownsU && (unsigned)(s.u - ulo) < (unsigned)ucnt);
-            M.mi = __ballot(ownsV && (unsigned)(s.i - vlo) < (unsigned)vcnt);
-            M.mj = __ballot(ownsV && (unsigned)(s.j - vlo) < (unsigned)vcnt);
+            M.mu = __ballot((unsigned)(s.u - Rlo) < rcnt);
+            M.mi = __ballot((unsigned)(s.i - Rlo) < rcnt);
+            M.mj = __ballot((unsigned)(s.j - Rlo) < rcnt);
             return M;
         };
         auto lane_sample = [&](const mfcd_sample &s, int tl) {     // record of lane tl as wave-uniform values
@@ -324,8 +323,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             return r;
         };
         auto touches = [&](const mfcd_sample &s, int R) {          // does the batch held in `s` touch virtual row R ?
-            const int r = rmap.table_row(R);
-            return (rmap.is_item(R) ? __ballot(s.i == r || s.j == r) : __ballot(s.u == r)) != 0ull;
+            return __ballot(s.u == R || s.i == R || s.j == R) != 0ull;
         };
 
         // Which batches touch a row of mine is known before the launch (touch_build_kernel: one pass over the call's
@@ -356,7 +354,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     const int tl = __ffsll((long long)pm) - 1;
                     pm &= pm - 1;
                     const mfcd_sample sk = lane_sample(rk, tl);
-                    const int rows[3] = {rmap.vrow_u(sk.u), rmap.vrow_v(sk.i), rmap.vrow_v(sk.j)};
+                    const int rows[3] = {sk.u, sk.i, sk.j};
                     const bool fl[3] = {(bool)((Mk.mu >> tl) & 1ull), (bool)((Mk.mi >> tl) & 1ull),
                                         (bool)((Mk.mj >> tl) & 1ull)};
 #pragma unroll
@@ -455,12 +453,9 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     const int64_t slot0 = (pos0 + base + tl) * 3;
-                    if ((M.mu >> tl) & 1ull)
-                        store_row(rmap.vrow_u(__shfl(s.u, tl, MFCD_WAVE)), slot0 + 0, (unsigned)step + 1u);
-                    if ((M.mi >> tl) & 1ull)
-                        store_row(rmap.vrow_v(__shfl(s.i, tl, MFCD_WAVE)), slot0 + 1, (unsigned)step + 1u);
-                    if ((M.mj >> tl) & 1ull)
-                        store_row(rmap.vrow_v(__shfl(s.j, tl, MFCD_WAVE)), slot0 + 2, (unsigned)step + 1u);
+                    if ((M.mu >> tl) & 1ull) store_row(__shfl(s.u, tl, MFCD_WAVE), slot0 + 0, (unsigned)step + 1u);
+                    if ((M.mi >> tl) & 1ull) store_row(__shfl(s.i, tl, MFCD_WAVE), slot0 + 1, (unsigned)step + 1u);
+                    if ((M.mj >> tl) & 1ull) store_row(__shfl(s.j, tl, MFCD_WAVE), slot0 + 2, (unsigned)step + 1u);
                 }
             }
         };

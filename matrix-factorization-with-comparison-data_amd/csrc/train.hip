@@ -420,7 +420,7 @@ constexpr size_t kColdBytes = 64;   // ResidentCold: six table pointers + paddin
 
 constexpr size_t kDbgBytes = 16 * 256 * 8 * 8;  // [<=4096 waves][8] u64 of the diagnostic build (tools/)
 
-ResidentLayout resident_layout(int64_t N, int B, int d)
+ResidentLayout resident_layout(int64_t N, int B, int n, int m, int d)
 {
     ResidentLayout L;
     const int64_t K = (N + B - 1) / B;
@@ -432,9 +432,8 @@ ResidentLayout resident_layout(int64_t N, int B, int d)
     off += align256(kColdBytes + sizeof(StepScalars) * (size_t)(K + 1));   // one pad entry: the kernel reads step k+1
     L.terms_off = off;
     off += align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
-    L.touch_off = off;   // per-wave touch strings of the look-ahead form (resident.hip)
-    off += align256(sizeof(unsigned) * (size_t)mfcd_detail::kResidentMaxWaves *
-                    (size_t)mfcd_detail::resident_touch_words((int)(K < 0x7fffff00 ? K : 0x7fffff00)));
+    L.touch_off = off;   // aux region of the resident form: row order, translated samples, touch strings (resident.hip)
+    off += d > 0 ? align256(mfcd_detail::resident_aux_bytes(N, n, m, (int)(K < 0x7fffff00 ? K : 0x7fffff00))) : 0;
     L.mailbox_off = off;
     L.mailbox_bytes = sizeof(unsigned long long) * (size_t)N * 3 * (size_t)d;
     off += align256(L.mailbox_bytes > 0 ? L.mailbox_bytes : 1);
@@ -455,7 +454,7 @@ bool resident_applies(int64_t N, int B, int n, int m, int d, mfcd_detail::Reside
     if (g_train_path == 1 || g_train_path == 3 || N <= 0) return false;
     const mfcd_detail::ResidentPlan pl = mfcd_detail::plan_resident(n, m, d, device_cus());
     if (!pl.ok) return false;
-    if (resident_layout(N, B, d).mailbox_bytes > kMaxMailboxBytes) return false;
+    if (resident_layout(N, B, n, m, d).mailbox_bytes > kMaxMailboxBytes) return false;
     if (out) *out = pl;
     return true;
 }
@@ -490,11 +489,11 @@ extern "C" size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int
     if (N < 0 || B <= 0 || n <= 0 || m <= 0 || d <= 0) return 0;
     size_t need = streaming_bytes(N, n, m, d);
     if (g_train_path != 1 && mfcd_detail::plan_resident(n, m, d, 256).ok) {
-        const ResidentLayout L = resident_layout(N, B, d);
+        const ResidentLayout L = resident_layout(N, B, n, m, d);
         if (L.mailbox_bytes <= kMaxMailboxBytes && L.total > need) need = L.total;
     }
     if (mfcd_detail::local_applies(N > 0 ? N : 1, B, n, m, d)) {
-        const ResidentLayout L = resident_layout(N, B, 0);   // the local form uses the same layout without a mailbox
+        const ResidentLayout L = resident_layout(N, B, n, m, 0);   // the local form uses the same layout without a mailbox
         if (L.total > need) need = L.total;
     }
     return need;
@@ -528,7 +527,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     if (g_train_path == 3 && !local) return MFCD_EINVAL;
     if constexpr (kF32) if (local) {
         if (nsteps > 0x7fffffff) return MFCD_EINVAL;
-        const ResidentLayout L = resident_layout(N, B, 0);   // status | dbg | cold | scalars | terms (no mailbox)
+        const ResidentLayout L = resident_layout(N, B, n, m, 0);   // status | dbg | cold | scalars | terms (no mailbox)
         char *base = (char *)workspace;
         StepScalars *sc_dev = (StepScalars *)(base + L.sc_off);
         float *terms_l = (float *)(base + L.terms_off);
@@ -580,7 +579,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     if constexpr (kF32) if (resident) {
         // ---- persistent register-resident form: ONE launch for all nsteps (resident.hip) ----
         if (nsteps > 0x7fffffff) return MFCD_EINVAL;
-        const ResidentLayout L = resident_layout(N, B, d);
+        const ResidentLayout L = resident_layout(N, B, n, m, d);
         char *base = (char *)workspace;
         StepScalars *sc_dev = (StepScalars *)(base + L.sc_off);
         float *terms_r = (float *)(base + L.terms_off);
@@ -612,7 +611,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
         if (int rc = mfcd_detail::launch_resident_steps(rp, base + L.cold_off, samples, N, B, n, m, d, sc_dev,
                                                        adam_static(beta1, beta2, eps, weight_decay), mailbox, terms_r,
                                                        status, (unsigned long long *)(base + L.dbg_off),
-                                                       (unsigned *)(base + L.touch_off), (int)nsteps, st))
+                                                       (void *)(base + L.touch_off), (int)nsteps, st))
             return rc;
         if (timing_us) MFCD_HIP_TRY(hipEventRecord(e1, st));
         if (loss_per_step) {

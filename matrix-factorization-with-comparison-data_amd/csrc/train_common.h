@@ -151,8 +151,10 @@ ResidentPlan plan_resident(int n, int m, int d, int num_cus);
 int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
                           const mfcd_sample *samples, int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev,
                           const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status,
-                          unsigned long long *dbg, unsigned *touch, int K, hipStream_t st);
+                          unsigned long long *dbg, void *aux, int K, hipStream_t st);
 int resident_touch_words(int K);   // dwords per wave of the touch strings for a call of K steps
+// bytes of the aux region launch_resident_steps carves up: row-order tables, translated samples, touch strings
+size_t resident_aux_bytes(int64_t N, int n, int m, int K);
 constexpr int kResidentMaxWaves = 4096;   // 256 CUs x 16 waves: upper bound of ResidentPlan::NW (workspace sizing)
 
 }  // namespace mfcd_detail
