@@ -30,6 +30,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 C2 = dict(n=4096, m=4096, d=64, p=0.01, s=1.0, K=1, B=64, lr=1e-3, wd=1e-5)
+# BASELINE.json configs[3], the configuration named for data parallelism (rehearsal only: --workload C4)
+C4 = dict(n=65536, m=65536, d=64, p=0.0005, s=1.0, K=4, B=64, lr=1e-3, wd=1e-5)
+WORKLOADS = {"C2": C2, "C4": C4}
 
 
 def make_workload(cfg, seed):
@@ -53,12 +56,18 @@ def make_workload(cfg, seed):
     u, i, j = keys // (m * m), (keys // m) % m, keys % m
     A, Bf = A.numpy().astype(np.float64), Bf.numpy().astype(np.float64)
     diff = np.einsum("td,td->t", A[u], Bf[i] - Bf[j])
-    z = (rng.random(want) < 1.0 / (1.0 + np.exp(-cfg["s"] * diff))).astype(np.float64)
-    rows = np.stack([u, i, j, z], 1).astype(np.float64)
+    prob = 1.0 / (1.0 + np.exp(-cfg["s"] * diff))
     n_tr, n_va = int(0.8 * want), int(0.1 * want)
+    K = int(cfg.get("K", 1))
+
+    def labelled(lo, hi, reps):   # K independent hard labels per training triplet (structure.py:493-519, soft_label=False)
+        idx = np.repeat(np.arange(lo, hi), reps)
+        z = (rng.random(idx.size) < prob[idx]).astype(np.float64)
+        return np.stack([u[idx], i[idx], j[idx], z], 1).astype(np.float64)
+
     U0 = (torch.randn(n, d, generator=g) / np.sqrt(d)).numpy()
     V0 = (torch.randn(m, d, generator=g) / np.sqrt(d)).numpy()
-    return rows[:n_tr], rows[n_tr:n_tr + n_va], U0, V0
+    return labelled(0, n_tr, K), labelled(n_tr, n_tr + n_va, 1), U0, V0
 
 
 def algorithmic_bytes_per_step(cfg):
@@ -180,7 +189,7 @@ def cpu_baseline(cfg, seed, budget_s=12.0):
         shutil.rmtree(tmp, ignore_errors=True)
     v, nsteps, dt = results[best]
     return {"value": round(v, 1), "unit": "triplet-updates/s", "cores": int(best), "kind": "port",
-            "sample": f"{nsteps} optimiser steps (B={B}) of the C2 workload in {dt:.1f}s, C oracle "
+            "sample": f"{nsteps} optimiser steps (B={B}) of the {cfg.get('name', 'C2')} workload in {dt:.1f}s, C oracle "
                       f"(oracle/mfcd_oracle.c, -O3 -march=native, OpenMP Adam sweep); host has {ncpu} usable cores",
             "by_threads": {str(k): round(r[0], 1) for k, r in results.items()},
             "torch_op_port_4thr": round(tp, 1)}
@@ -220,6 +229,9 @@ def _run():
                     help="form of the data-parallel path (default native: the loop inside libmfcd_hip.so with one RCCL "
                          "all-gather per step; allgather / allreduce: the per-step torch.distributed loops); given "
                          "with --gpus 1 it rehearses that path on a one-rank group")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C2",
+                    help="C2 (default): the configuration the metric is quoted on; C4: BASELINE.json configs[3], for "
+                         "rehearsing the data-parallel path at the size it is named for")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -231,7 +243,8 @@ def _run():
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cfg = dict(C2)
+    cfg = dict(WORKLOADS[args.workload])
+    cfg["name"] = args.workload
 
     if world > 1 or args.dp_mode:
         import torch.distributed as dist
@@ -275,8 +288,9 @@ def _run():
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 6),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: n=m=4096 d=64 p=0.01 random triplets, B=64, Adam lr=1e-3 wd=1e-5, "
-                               "1049 steps/epoch + validation pass per epoch", "global_batch": cfg["B"],
+        "config": {"workload": f"{cfg['name']}: n={cfg['n']} m={cfg['m']} d={cfg['d']} p={cfg['p']} K={cfg['K']} random triplets, "
+                               f"B={cfg['B']}, Adam lr=1e-3 wd=1e-5, {runner.steps_per_epoch} steps/epoch + validation "
+                               "pass per epoch", "global_batch": cfg["B"],
                    "train_samples": runner.train.N, "parallelism": "single"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -297,8 +297,9 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3 / steps, 6),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: n=m=4096 d=64 p=0.01 random triplets, per-GPU batch 64, Adam lr=1e-3 wd=1e-5, "
-                               "validation pass per epoch", "global_batch": Bg, "train_samples": train.N,
+        "config": {"workload": f"{cfg.get('name', 'C2')}: n={cfg['n']} m={cfg['m']} d={cfg['d']} p={cfg['p']} K={cfg.get('K', 1)} "
+                               "random triplets, per-GPU batch 64, Adam lr=1e-3 wd=1e-5, validation pass per epoch",
+                   "global_batch": Bg, "train_samples": train.N,
                    "parallelism": f"dp{world} ({what})",
                    "replicas_in_sync": in_sync},
         "roofline": {"bound": "hbm", "achieved": round(abytes / (dt / steps) / 1e9, 1), "peak": bench_mod.HBM_PEAK_GBS,

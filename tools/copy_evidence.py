@@ -9,7 +9,8 @@ cp(newest(E + "/prof_bench/runc/*_kernel_stats.csv"), "r01_bench_c2_kernel_stats
 cp(newest(E + "/prof_dp/runc/*_kernel_stats.csv"), "r01_bench_c2_dp_native_one_rank_kernel_stats.csv")
 cp(newest(E + "/prof_uvt/runc/*_kernel_stats.csv"), "r01_uvt_pass_kernel_stats.csv")
 for name in ("bench_c2_under_rocprof.json", "bench_c2_final_run.json", "bench_c2_dp_native_one_rank.json",
-             "uvt_pass_roofline.txt", "metric_functions_c2.txt"):
+             "bench_c4_single.json", "bench_c4_dp_native_one_rank.json", "uvt_pass_roofline.txt",
+             "metric_functions_c2.txt"):
     cp(os.path.join(E, name), "r01_" + name)
 cp(os.path.join(E, "pmc_traffic.json"), "pmc_traffic.json")
 for tag, name in (("pmc_fetch", "r01_resident_pmc_fetch_size.csv"), ("pmc_write", "r01_resident_pmc_write_size.csv")):

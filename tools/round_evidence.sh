@@ -10,6 +10,9 @@ timeout -k 10 300 python bench.py > $E/bench_c2_final_run.json 2> $E/bench_c2_fi
 cut -c1-400 $E/bench_c2_final_run.json
 timeout -k 10 300 python bench.py --dp-mode native --no-cpu-baseline > $E/bench_c2_dp_native_one_rank.json 2>/dev/null
 cut -c1-200 $E/bench_c2_dp_native_one_rank.json
+timeout -k 10 600 python bench.py --workload C4 --no-cpu-baseline --steps 2000 --warmup 200 > $E/bench_c4_single.json 2>/dev/null
+timeout -k 10 600 python bench.py --workload C4 --dp-mode native --no-cpu-baseline --steps 2000 --warmup 200 > $E/bench_c4_dp_native_one_rank.json 2>/dev/null
+cut -c1-160 $E/bench_c4_single.json $E/bench_c4_dp_native_one_rank.json
 timeout -k 10 300 python tools/bench_uvt.py > $E/uvt_pass_roofline.txt 2>&1
 cat $E/uvt_pass_roofline.txt | cut -c1-230
 timeout -k 10 300 python tools/bench_metrics.py > $E/metric_functions_c2.txt 2>&1 || true
