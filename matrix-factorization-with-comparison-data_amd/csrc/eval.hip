@@ -1,13 +1,16 @@
 // eval.hip — no-grad forward + BCE pass (validation loop structure.py:858-868, evaluate_model
-// structure.py:899-916) and sample validation.  One workgroup per batch of B samples; one wave per
-// sample for the row gathers (coalesced d-float rows) and the 64-lane shuffle reduction; the batch
+// structure.py:899-916) and sample validation.  One workgroup of 16 waves per batch of B samples; one wave per
+// sample for the row gathers (coalesced d-float rows) and the 64-lane shuffle reduction (a wave handles every 16th
+// sample of the batch: the pass is a chain of dependent gathers, so it wants waves, not bytes); the batch
 // mean and the match count are reduced in a fixed order, so results are run-to-run identical.
 #include "common.h"
 
 namespace {
 
+constexpr int kEvalWaves = 16;
+
 template <typename TP>
-__global__ __launch_bounds__(256) void eval_batches_kernel(const TP *__restrict__ U, const TP *__restrict__ V,
+__global__ __launch_bounds__(kEvalWaves * 64) void eval_batches_kernel(const TP *__restrict__ U, const TP *__restrict__ V,
                                                            const mfcd_sample *__restrict__ samples, int64_t N, int B,
                                                            int d, float *__restrict__ loss_per_batch,
                                                            int32_t *__restrict__ correct_per_batch,
@@ -18,7 +21,7 @@ __global__ __launch_bounds__(256) void eval_batches_kernel(const TP *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t off = (int64_t)blockIdx.x * B;
     const int b = (int)((N - off) < B ? (N - off) : B);
-    for (int t = wave; t < b; t += 4) {
+    for (int t = wave; t < b; t += kEvalWaves) {
         const mfcd_sample s = samples[off + t];
         const float p = sigmoid_f32(wave_score(U, V, s.u, s.i, s.j, d, lane));
         if (lane == 0) {
@@ -67,7 +70,7 @@ int eval_batches_impl(const TP *U, const TP *V, const mfcd_sample *samples, int6
     if (N == 0) return 0;
     if (!samples || !loss_per_batch) return MFCD_EINVAL;
     const int64_t nb = (N + B - 1) / B;
-    hipLaunchKernelGGL((eval_batches_kernel<TP>), dim3((unsigned)nb), dim3(256), sizeof(float) * 2 * (size_t)B,
+    hipLaunchKernelGGL((eval_batches_kernel<TP>), dim3((unsigned)nb), dim3(kEvalWaves * 64), sizeof(float) * 2 * (size_t)B,
                        (hipStream_t)stream, U, V, samples, N, B, d, loss_per_batch, correct_per_batch, p_out);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
