@@ -64,6 +64,8 @@ __host__ __device__ inline RowMap make_row_map(int n, int m)
 #ifdef MFCD_STAMPS
 #define STAMP() ((u64)__builtin_amdgcn_s_memtime())
 #define DBG_ADD(slot, val) dbg_acc[slot] += (val)
+// MFCD_STAMPS=2 ("light"): no stamp on the common path — slot 3 = whole hit block of a step (record load .. last hit),
+// slot 4 = publish slow path only, slot 7 = number of publish slow paths — so that the step loop keeps its timing
 #else
 #define STAMP() ((u64)0)
 #define DBG_ADD(slot, val) ((void)0)
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         }
     }
 #ifdef MFCD_STAMPS
+    [[maybe_unused]] u64 dbg_rt_age = 0, dbg_rt_n = 0;
     u64 dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const u64 t_start = STAMP();
 #endif
@@ -252,6 +255,21 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         }
         [[maybe_unused]] const u64 t_poll1 = STAMP();
         DBG_ADD(1, t_poll1 - t_poll0);
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+        if (spins > 0) {   // waited: how old is the publish, and was it issued after I started polling ?
+            const u64 now_rt = (u64)__builtin_amdgcn_s_memrealtime();
+            u64 newest = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (!own[r]) {
+                    const u64 tp = __hip_atomic_load(a.mailbox + (int64_t)a.N * 3 * D + pos * 3 + r, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                    newest = tp > newest ? tp : newest;
+                }
+            dbg_rt_age += now_rt - newest;                      // success time - (latest) publish time, 10 ns units
+            dbg_rt_n += 1;
+        }
+#endif
         DBG_ADD(5, 1);
         DBG_ADD(6, spins);
 
@@ -338,6 +356,9 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             u64 cand = win & (1ull << W);
             if (first || (win & 1ull)) cand |= win & ((1ull << W) - 2ull);   // bits 1 .. W-1
             if (cand == 0ull) return;                              // the common case
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+            const u64 t_pub0 = STAMP();
+#endif
             // slow path: bring the whole window's records in with ONE burst of independent loads
             mfcd_sample wrec[W + 1];
 #pragma unroll
@@ -388,6 +409,12 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                         }
                         u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + r) * D;
                         const unsigned tag = (unsigned)k + 1u;
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+                        if (lane == 0)   // publish time (100 MHz real-time clock), behind the mailbox
+                            __hip_atomic_store(a.mailbox + (int64_t)a.N * 3 * D + ((int64_t)k * a.B + tl) * 3 + r,
+                                               (u64)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+#endif
                         if constexpr (D >= 64) {
 #pragma unroll
                             for (int s2 = 0; s2 < S; ++s2) store_granule(dst + s2 * 64 + lane, tag, pp[s2]);
@@ -397,6 +424,10 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     }
                 }
             }
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+            DBG_ADD(4, STAMP() - t_pub0);
+            DBG_ADD(7, 1);
+#endif
         };
 
         publish_phase(-1, true);
@@ -417,6 +448,9 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #pragma unroll
             for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
             if (win & 1ull) {
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+                const u64 t_hit0 = STAMP();
+#endif
                 const mfcd_sample rk = load_rec(k);
                 const Masks M0 = role_masks(rk);
                 const int64_t pos0 = (int64_t)k * a.B;
@@ -430,7 +464,15 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     const bool ok = process_hit(lane_sample(rk, tl), M0, tl, pos0 + tl, (unsigned)k + 1u, inv_batch);
                     if (__builtin_amdgcn_readfirstlane((int)!ok)) return;
                 }
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+                DBG_ADD(3, STAMP() - t_hit0);
+#endif
             }
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+            // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
+            adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc_cur);
+            publish_phase(k, false);
+#else
             [[maybe_unused]] const u64 t_adam0 = STAMP();
             // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
             adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc_cur);
@@ -438,6 +480,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             DBG_ADD(3, t_adam1 - t_adam0);
             publish_phase(k, false);
             DBG_ADD(4, STAMP() - t_adam1);
+#endif
             sc_cur = sc_next;
         }
     } else {
@@ -490,6 +533,10 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 
 #ifdef MFCD_STAMPS
     dbg_acc[0] = STAMP() - t_start;
+#if MFCD_STAMPS == 2
+    dbg_acc[2] = dbg_rt_age;   // light mode: slot 2 = sum of (success - publish) over waited polls [10 ns], slot 6 spins
+    dbg_acc[5] = dbg_acc[5] | (dbg_rt_n << 32);   // high half: number of waited polls
+#endif
     if (lane == 0 && a.dbg)
         for (int x = 0; x < 8; ++x) a.dbg[(int64_t)gw * 8 + x] = dbg_acc[x];
 #endif

@@ -436,7 +436,12 @@ ResidentLayout resident_layout(int64_t N, int B, int n, int m, int d)
     off += d > 0 ? align256(mfcd_detail::resident_aux_bytes(N, n, m, (int)(K < 0x7fffff00 ? K : 0x7fffff00))) : 0;
     L.mailbox_off = off;
     L.mailbox_bytes = sizeof(unsigned long long) * (size_t)N * 3 * (size_t)d;
+#ifdef MFCD_STAMPS
+    // diagnostic build: publish timestamps, one u64 per (sample, role), directly behind the mailbox
+    off += align256((L.mailbox_bytes > 0 ? L.mailbox_bytes : 1) + sizeof(unsigned long long) * (size_t)N * 3);
+#else
     off += align256(L.mailbox_bytes > 0 ? L.mailbox_bytes : 1);
+#endif
     L.total = off;
     return L;
 }
