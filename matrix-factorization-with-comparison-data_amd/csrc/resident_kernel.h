@@ -363,6 +363,11 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             mfcd_sample wrec[W + 1];
 #pragma unroll
             for (int b2 = 0; b2 <= W; ++b2) wrec[b2] = load_rec(j + b2 >= 0 ? j + b2 : a.K + 1);
+            // the per-step scalars of the roll-forward travel in the same burst (inside the loops below each would be a
+            // dependent load on the publish path); the table holds K+1 entries
+            StepScalars scw[W];
+#pragma unroll
+            for (int b2 = 1; b2 < W; ++b2) scw[b2] = a.sc[(j + b2) < a.K ? (j + b2) : a.K];
 #pragma unroll
             for (int kk = 1; kk <= W; ++kk) {
                 const int k = j + kk;
@@ -403,9 +408,9 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                         }
 #pragma unroll
                         for (int b2 = 1; b2 < kk; ++b2) {
-                            const StepScalars scb = a.sc[j + b2];
 #pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scb);
+                            for (int s2 = 0; s2 < S; ++s2)
+                                adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b2]);
                         }
                         u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + r) * D;
                         const unsigned tag = (unsigned)k + 1u;
