@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256) void resident_translate_kernel(const mfcd_samp
     const int k = (int)(t / B);
     const unsigned bit = 1u << (k & 31);
     const int word = k >> 5;
-    const int wu = s.u / rows_per_wave, wi = s.i / rows_per_wave, wj = s.j / rows_per_wave;
+    // one string per wave, or (rows_per_wave <= 4) one per virtual row: the kernel's ROWWIN
+    const int gr = rows_per_wave <= 4 ? 1 : rows_per_wave;
+    const int wu = s.u / gr, wi = s.i / gr, wj = s.j / gr;
     atomicOr(touch + (size_t)wu * KW + word, bit);
     if (wi != wu) atomicOr(touch + (size_t)wi * KW + word, bit);
     if (wj != wi && wj != wu) atomicOr(touch + (size_t)wj * KW + word, bit);
@@ -138,7 +140,7 @@ size_t resident_aux_bytes(int64_t N, int n, int m, int K)
 {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     return al(sizeof(int) * (size_t)(n + m)) * 2 + al(sizeof(mfcd_sample) * (size_t)(N > 0 ? N : 1)) +
-           al(sizeof(unsigned) * (size_t)kResidentMaxWaves * (size_t)resident_touch_words(K));
+           al(sizeof(unsigned) * (size_t)(4 * kResidentMaxWaves + 4) * (size_t)resident_touch_words(K));   // <= 4 rows/wave
 }
 
 int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
@@ -173,7 +175,8 @@ int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
     const unsigned sblocks = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(resident_order_kernel, dim3((unsigned)((n + m + 255) / 256)), dim3(256), 0, st, n, m, vrow, inv);
     const int want_touch = a.lookahead > 0 && B <= 64;   // the look-ahead form reads the per-wave touch strings
-    if (want_touch) MFCD_HIP_TRY(hipMemsetAsync(touch, 0, sizeof(unsigned) * (size_t)pl.NW * a.KW, st));
+    if (want_touch)   // one string per wave, or per row for waves of up to 4 rows (resident_kernel.h ROWWIN)
+        MFCD_HIP_TRY(hipMemsetAsync(touch, 0, sizeof(unsigned) * (size_t)pl.NW * (rpw <= 4 ? rpw : 1) * a.KW, st));
     hipLaunchKernelGGL(resident_translate_kernel, dim3(sblocks), dim3(256), 0, st, samples, N, B, n, vrow, rpw, a.KW,
                        want_touch, xs, touch);
     const char *fm = getenv("MFCD_RESIDENT_MATH");   // experiment knob: "ieee" / "fast" overrides mfcd_set_resident_math

@@ -344,12 +344,27 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             return __ballot(s.u == R || s.i == R || s.j == R) != 0ull;
         };
 
-        // Which batches touch a row of mine is known before the launch (touch_build_kernel: one pass over the call's
-        // samples).  `win` is a sliding window over my bit string: bit b <-> batch j + b, j = the step just finished;
-        // it replaces a per-step record load + range test + ballot per wave (every wave scanning every batch).
-        const unsigned *const tw = a.touch + (size_t)__builtin_amdgcn_readfirstlane(gw) * a.KW;
-        u64 win = (u64)tw[0] << 1;   // j = -1: "batch -1" is empty
-        int fill = 33, widx = 1;     // bits 0 .. fill-1 of win are valid; the next dword of the string goes to bit `fill`
+        // Which batches touch a row of mine is known before the launch (resident_translate_kernel: one pass over the
+        // call's samples).  A sliding window over such a bit string — bit b <-> batch j + b, j = the step just finished —
+        // replaces a per-step record load + range test + ballot per wave (every wave scanning every batch).
+        // Waves of up to 4 rows keep one window PER ROW (a.touch then holds one string per virtual row): which row is
+        // due for publishing, and for which step, is then decided with scalar bit tests alone, and the publish path
+        // fetches only the records of the batches it actually publishes for.
+        constexpr int RPW = EW / D;                 // rows per wave
+        constexpr bool ROWWIN = RPW <= 4;
+        constexpr int NWIN = ROWWIN ? RPW : 1;
+        const int gws = __builtin_amdgcn_readfirstlane(gw);
+        const unsigned *tw[NWIN];
+        u64 winR[NWIN];
+#pragma unroll
+        for (int r = 0; r < NWIN; ++r) {
+            tw[r] = a.touch + (size_t)(ROWWIN ? gws * RPW + r : gws) * a.KW;
+            winR[r] = (u64)tw[r][0] << 1;           // j = -1: "batch -1" is empty
+        }
+        u64 win = winR[0];                          // any of my rows
+#pragma unroll
+        for (int r = 1; r < NWIN; ++r) win |= winR[r];
+        int fill = 33, widx = 1;     // bits 0 .. fill-1 of the windows are valid; the next dword of a string goes to bit `fill`
 
         // publish, from the state after step j, every (k, R) whose turn it is (see the template comment)
         auto publish_phase = [&](int j, bool first) {
@@ -359,6 +374,80 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
             const u64 t_pub0 = STAMP();
 #endif
+            if constexpr (ROWWIN) {
+                // per-row windows: (row r, step k = j + kk) is due iff batch k touches the row, no batch in (j, k) does,
+                // and either k has just entered the window (kk == W) or the row was touched by batch j itself (its
+                // value for k could not be known earlier) — the same rule as below, read off the bit strings
+                StepScalars scw[W];
+                bool have_sc = false;
+#pragma unroll
+                for (int r = 0; r < NWIN; ++r) {
+                    const u64 wr = winR[r];
+                    const bool fresh = first || (wr & 1ull);
+#pragma unroll
+                    for (int kk = 1; kk <= W; ++kk) {
+                        const int k = j + kk;
+                        if (!((wr >> kk) & 1ull) || k >= a.K) continue;
+                        if (wr & ((1ull << kk) - 2ull)) continue;          // touched again in (j, k): published later
+                        if (kk < W && !fresh) continue;                    // published when k entered the window
+                        const int R = Rlo + r;
+                        const mfcd_sample rk = load_rec(k);
+                        if (!have_sc) {                                    // roll-forward scalars, same burst
+#pragma unroll
+                            for (int b2 = 1; b2 < W; ++b2) scw[b2] = a.sc[(j + b2) < a.K ? (j + b2) : a.K];
+                            have_sc = true;
+                        }
+                        // roll the registers of row R forward over steps j+1 .. k-1 (dense-only updates)
+                        const int q0 = reg_of(R);
+                        float pp[S], mm1[S], mm2[S];
+#pragma unroll
+                        for (int s2 = 0; s2 < S; ++s2) pp[s2] = mm1[s2] = mm2[s2] = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            if (q >= q0 && q < q0 + S) {
+                                const int s2 = D >= 64 ? (q * 64 % D) / 64 : 0;
+                                pp[s2] = p[q];
+                                mm1[s2] = m1[q];
+                                mm2[s2] = m2[q];
+                            }
+                        }
+#pragma unroll
+                        for (int b2 = 1; b2 < kk; ++b2) {
+#pragma unroll
+                            for (int s2 = 0; s2 < S; ++s2)
+                                adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b2]);
+                        }
+                        const u64 mr[3] = {(u64)__ballot(rk.u == R), (u64)__ballot(rk.i == R), (u64)__ballot(rk.j == R)};
+                        const unsigned tag = (unsigned)k + 1u;
+#pragma unroll
+                        for (int role = 0; role < 3; ++role) {
+                            u64 pm = mr[role];
+                            while (pm) {
+                                const int tl = __ffsll((long long)pm) - 1;
+                                pm &= pm - 1;
+                                u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + role) * D;
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+                                if (lane == 0)   // publish time (100 MHz real-time clock), behind the mailbox
+                                    __hip_atomic_store(a.mailbox + (int64_t)a.N * 3 * D + ((int64_t)k * a.B + tl) * 3 + role,
+                                                       (u64)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+#endif
+                                if constexpr (D >= 64) {
+#pragma unroll
+                                    for (int s2 = 0; s2 < S; ++s2) store_granule(dst + s2 * 64 + lane, tag, pp[s2]);
+                                } else {
+                                    if (lane / D == (R - Rlo) % RPR) store_granule(dst + lcol, tag, pp[0]);
+                                }
+                            }
+                        }
+                    }
+                }
+#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
+                DBG_ADD(4, STAMP() - t_pub0);
+                DBG_ADD(7, 1);
+#endif
+                return;
+            }
             // slow path: bring the whole window's records in with ONE burst of independent loads
             mfcd_sample wrec[W + 1];
 #pragma unroll
@@ -440,14 +529,19 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         StepScalars sc_cur = a.sc[0];
         const StepScalars *sc_ptr = a.sc + 1;      // running pointer: the table holds K+1 entries (host pads one)
         for (int k = 0; k < a.K; ++k) {
-            // slide the window: bit 0 becomes batch k
-            win >>= 1;
+            // slide the windows: bit 0 becomes batch k
             --fill;
+#pragma unroll
+            for (int r = 0; r < NWIN; ++r) winR[r] >>= 1;
             if (fill < 16) {
-                win |= (u64)tw[widx] << fill;
+#pragma unroll
+                for (int r = 0; r < NWIN; ++r) winR[r] |= (u64)tw[r][widx] << fill;
                 ++widx;
                 fill += 32;
             }
+            win = winR[0];
+#pragma unroll
+            for (int r = 1; r < NWIN; ++r) win |= winR[r];
             const StepScalars sc_next = *sc_ptr++;
 
 #pragma unroll
