@@ -367,9 +367,15 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         int fill = 33, widx = 1;     // bits 0 .. fill-1 of the windows are valid; the next dword of a string goes to bit `fill`
 
         // publish, from the state after step j, every (k, R) whose turn it is (see the template comment)
-        auto publish_phase = [&](int j, bool first) {
+        // phase (per-row windows only): 0 everything, from the state after step j (the initial call);
+        //   1 BEFORE step j's own hits and update: the rows batch j does not touch — their value after step j is a
+        //     dense-only update away, so it is published now and does not wait behind this wave's hit of the step;
+        //   2 after the update: the rows batch j touched.
+        auto publish_phase = [&](int j, bool first, int phase, const StepScalars &sc_j) {
             u64 cand = win & (1ull << W);
             if (first || (win & 1ull)) cand |= win & ((1ull << W) - 2ull);   // bits 1 .. W-1
+            if (phase == 1) cand = win & (1ull << W);
+            if (phase == 2 && !(win & 1ull)) cand = 0ull;
             if (cand == 0ull) return;                              // the common case
 #if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
             const u64 t_pub0 = STAMP();
@@ -384,6 +390,8 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                 for (int r = 0; r < NWIN; ++r) {
                     const u64 wr = winR[r];
                     const bool fresh = first || (wr & 1ull);
+                    if (phase == 1 && (wr & 1ull)) continue;               // touched by batch j: after the update
+                    if (phase == 2 && !(wr & 1ull)) continue;              // done before the update
 #pragma unroll
                     for (int kk = 1; kk <= W; ++kk) {
                         const int k = j + kk;
@@ -410,6 +418,10 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                                 mm1[s2] = m1[q];
                                 mm2[s2] = m2[q];
                             }
+                        }
+                        if (phase == 1) {                                  // step j itself: dense-only for this row
+#pragma unroll
+                            for (int s2 = 0; s2 < S; ++s2) adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, sc_j);
                         }
 #pragma unroll
                         for (int b2 = 1; b2 < kk; ++b2) {
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #endif
         };
 
-        publish_phase(-1, true);
+        publish_phase(-1, true, 0, a.sc[0]);
 
         StepScalars sc_cur = a.sc[0];
         const StepScalars *sc_ptr = a.sc + 1;      // running pointer: the table holds K+1 entries (host pads one)
@@ -546,6 +558,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 
 #pragma unroll
             for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
+            if constexpr (ROWWIN) publish_phase(k, false, 1, sc_cur);
             if (win & 1ull) {
 #if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
                 const u64 t_hit0 = STAMP();
@@ -570,14 +583,14 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
             // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
             adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc_cur);
-            publish_phase(k, false);
+            publish_phase(k, false, ROWWIN ? 2 : 0, sc_cur);
 #else
             [[maybe_unused]] const u64 t_adam0 = STAMP();
             // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
             adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc_cur);
             [[maybe_unused]] const u64 t_adam1 = STAMP();
             DBG_ADD(3, t_adam1 - t_adam0);
-            publish_phase(k, false);
+            publish_phase(k, false, ROWWIN ? 2 : 0, sc_cur);
             DBG_ADD(4, STAMP() - t_adam1);
 #endif
             sc_cur = sc_next;
