@@ -559,6 +559,10 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #pragma unroll
             for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
             if constexpr (ROWWIN) publish_phase(k, false, 1, sc_cur);
+            // a wave with a hit or a fresh publish is on somebody's critical chain, the waves on the common path have
+            // slack: it issues ahead of them until its step is done
+            const bool urgent = (win & 1ull) != 0ull;
+            if (urgent) __builtin_amdgcn_s_setprio(3);
             if (win & 1ull) {
 #if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
                 const u64 t_hit0 = STAMP();
@@ -584,6 +588,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
             adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc_cur);
             publish_phase(k, false, ROWWIN ? 2 : 0, sc_cur);
+            if (urgent) __builtin_amdgcn_s_setprio(0);
 #else
             [[maybe_unused]] const u64 t_adam0 = STAMP();
             // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
@@ -591,6 +596,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             [[maybe_unused]] const u64 t_adam1 = STAMP();
             DBG_ADD(3, t_adam1 - t_adam0);
             publish_phase(k, false, ROWWIN ? 2 : 0, sc_cur);
+            if (urgent) __builtin_amdgcn_s_setprio(0);
             DBG_ADD(4, STAMP() - t_adam1);
 #endif
             sc_cur = sc_next;
