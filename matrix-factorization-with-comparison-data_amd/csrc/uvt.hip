@@ -732,7 +732,9 @@ UvtWs plan_ws(char *base, int n, int m, int d)
         const int64_t by_l2 = ((int64_t)m * d * 4 + (2 << 20) - 1) / (2 << 20);
         if (by_l2 > want) want = by_l2;
         int splits = want <= 1 ? 1 : (int)((want + 7) / 8 * 8);
-        const int max_splits = stages / 2 > 0 ? stages / 2 : 1;
+        // at least 8 stages per workgroup where the column count allows: the prologue (U fragment, first stage) is worth
+        // ~1.5 stages (C2: 8 splits 77.8 us, 32 splits 83.6 us for the whole pass)
+        const int max_splits = stages / 8 > 0 ? stages / 8 : (stages / 2 > 0 ? stages / 2 : 1);
         if (splits > max_splits) splits = max_splits >= 8 ? max_splits / 8 * 8 : max_splits;
         if (splits > 256) splits = 256;
         const int per = (stages + splits - 1) / splits;
