@@ -28,6 +28,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD (155 TF measured)
+# Vector-issue roofline of the register-resident form (same guide, cycle constants): 256 CUs x 4 SIMD-32 at 2.4 GHz;
+# a wave64 VALU instruction occupies its SIMD for 2 cycles, a transcendental (v_rcp / v_sqrt) for 8.
+SIMDS, CLOCK_GHZ, CYC_PLAIN, CYC_TRANS = 1024, 2.4, 2, 8
+# csrc/train_common.h adam_update_fast: 16 plain fp32 instructions + v_sqrt + v_rcp per element register of a wave
+ADAM_FAST_PLAIN, ADAM_FAST_TRANS = 16, 2
 
 C2 = dict(n=4096, m=4096, d=64, p=0.01, s=1.0, K=1, B=64, lr=1e-3, wd=1e-5)
 # BASELINE.json configs[3], the configuration named for data parallelism (rehearsal only: --workload C4)
@@ -75,6 +81,53 @@ def algorithmic_bytes_per_step(cfg):
     return 24 * (cfg["n"] + cfg["m"]) * cfg["d"] + 12 * cfg["B"] * cfg["d"] + 16 * cfg["B"]
 
 
+def algorithmic_valu_cycles_per_step(cfg):
+    """Vector-issue cycles one optimiser step NEEDS when the state lives in registers: the dense Adam update of every
+    element, nothing else (row exchange, bookkeeping and waits are overhead, not work): (n+m)*d/64 wave-registers x
+    (16 plain x 2 cycles + 2 transcendental x 8 cycles)."""
+    regs = (cfg["n"] + cfg["m"]) * cfg["d"] / 64.0
+    return regs * (ADAM_FAST_PLAIN * CYC_PLAIN + ADAM_FAST_TRANS * CYC_TRANS)
+
+
+def roofline_record(cfg, plan, period_us, kernel_us=None):
+    """`roofline` object for the form that actually ran (engine.train_plan), per optimiser step.
+    Streaming form: HBM-bound, achieved = algorithmic bytes / period.  Resident / local forms: the state never leaves
+    registers (LDS), so the byte model does not apply; the bound is vector issue, achieved = the Adam update's own
+    issue cycles / period against 1024 SIMDs x 2.4 GHz, and the HBM-equivalent rate is reported beside it, labelled."""
+    abytes = algorithmic_bytes_per_step(cfg)
+    hbm_equiv = abytes / (period_us * 1e-6) / 1e9
+    if plan["form_name"] == "streaming":
+        rec = {"bound": "hbm", "achieved": round(hbm_equiv, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(hbm_equiv / HBM_PEAK_GBS, 4), "traffic": None,
+               "algorithmic_bytes_per_launch": abytes,
+               "kernel": f"train_step_kernel<VEC={plan['streaming_vec']},CHUNKS={plan['streaming_chunks']}> "
+                         f"({plan['streaming_blocks']} workgroups; one launch per optimiser step)"}
+    else:
+        cyc = algorithmic_valu_cycles_per_step(cfg)
+        simds = SIMDS if plan["form_name"] == "resident" else 4      # the local form runs on ONE CU
+        peak = simds * CLOCK_GHZ                                     # G issue-cycles per second
+        ach = cyc / (period_us * 1e-6) / 1e9
+        kern = (f"resident_train_kernel<D={cfg['d']},Q={plan['resident_q']},LOOK={plan['resident_lookahead']},"
+                f"{'fast' if plan['fast_math'] else 'ieee'}> ({plan['resident_waves']} waves; persistent: one launch per "
+                "call, figures are per optimiser step = launch time / steps)") if plan["form_name"] == "resident" else \
+               "local_train_kernel (one workgroup, parameters in LDS; persistent: one launch per call)"
+        rec = {"bound": "valu-issue", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "Gcycle/s",
+               "frac": round(ach / peak, 4), "traffic": None,
+               "algorithmic_valu_cycles_per_launch_step": round(cyc, 1),
+               "valu_cycle_prices": {"plain_fp32": CYC_PLAIN, "transcendental": CYC_TRANS,
+                                     "adam_fast_instructions": [ADAM_FAST_PLAIN, ADAM_FAST_TRANS]},
+               "hbm_equivalent": {"GBps": round(hbm_equiv, 1), "frac_of_8TBps": round(hbm_equiv / HBM_PEAK_GBS, 4),
+                                  "algorithmic_bytes_per_step": abytes,
+                                  "note": "bytes a streaming step would move; this form keeps them in registers"},
+               "traffic_note": "null: no counter pass ran inside this process; offline rocprofv3 --pmc figures for this "
+                               "kernel are under profiles/ (README there names the file per round)",
+               "kernel": kern}
+    rec["launch_period_us"] = round(period_us, 3)
+    if kernel_us is not None:
+        rec["kernel_us_event_pairs"] = {k: round(v, 3) for k, v in zip(("avg", "min", "max"), kernel_us)}
+    return rec
+
+
 class Runner:
     """Consumes optimiser steps exactly like mfcd.engine.fit, but in step-counted slices."""
 
@@ -97,6 +150,15 @@ class Runner:
         self.stream, self.pos = None, 0
         self.pre = engine.StreamPrefetch(dev)   # next epoch's record stream is built under the running step kernel
         self.train_events = []  # (start, stop, launches) around each fused-step call in the timed region
+        # the workspace is planned ONCE for an epoch (as engine.fit does): no call of the run re-plans or re-initialises it
+        engine.reserve_workspace(self.train.N, cfg["B"], cfg["n"], cfg["m"], cfg["d"], dev)
+        self.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(64)]
+
+    def _event(self):
+        return self.event_pool.pop() if self.event_pool else torch.cuda.Event(enable_timing=True)
+
+    def reset_events(self):
+        self.train_events = []
 
     def run(self, steps, record=False):
         """Enqueue `steps` optimiser steps (+ a validation pass after every completed epoch). No host sync.
@@ -111,7 +173,7 @@ class Runner:
             take = min(left, steps)
             lo, hi = self.pos * B, min(self.train.N, (self.pos + take) * B)
             if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = self._event(), self._event()
                 e0.record()
             self.engine.train_steps(self.bind, self.stream[lo:hi], B)
             if record:
@@ -155,14 +217,14 @@ def cpu_baseline(cfg, seed, budget_s=12.0):
         orc = O.COracle(lib)
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         results = {}
-        for threads in sorted({1, min(ncpu, 16)}):
+        for threads in sorted({1, min(ncpu, 16), ncpu}):   # 1 thread, 16 threads, ALL host cores
             st = O.new_state(U0, V0)
             probe = tr[: 32 * B]
             t0 = time.perf_counter()
             orc.train_steps(st, probe[:, 0], probe[:, 1], probe[:, 2], probe[:, 3], B, 0, lr=cfg["lr"], wd=cfg["wd"],
                             threads=threads)
             per = (time.perf_counter() - t0) / 32
-            nsteps = int(max(64, min(200000, (budget_s / 2) / max(per, 1e-6))))
+            nsteps = int(max(64, min(200000, (budget_s / 3) / max(per, 1e-6))))
             reps = (nsteps * B + len(tr) - 1) // len(tr)
             sample = np.tile(tr, (reps, 1))[: nsteps * B]   # several epochs' worth of the same workload
             t0 = time.perf_counter()
@@ -192,7 +254,10 @@ def cpu_baseline(cfg, seed, budget_s=12.0):
             "sample": f"{nsteps} optimiser steps (B={B}) of the {cfg.get('name', 'C2')} workload in {dt:.1f}s, C oracle "
                       f"(oracle/mfcd_oracle.c, -O3 -march=native, OpenMP Adam sweep); host has {ncpu} usable cores",
             "by_threads": {str(k): round(r[0], 1) for k, r in results.items()},
-            "torch_op_port_4thr": round(tp, 1)}
+            "all_cores": {"cores": int(ncpu), "value": round(results[ncpu][0], 1)},
+            "torch_op_port_4thr": round(tp, 1),
+            "reference_vs_port": "profiles/r02_reference_vs_port_cpu.txt (build container: the unmodified reference's "
+                                 "step time beside this port's, same data)"}
 
 
 class _StdoutToStderr:
@@ -212,39 +277,122 @@ class _StdoutToStderr:
         return False
 
 
+def uvt_record(dev, U2, V2):
+    """Dense UV^T metric pass (mfcd_uvt_stats: fp32 MFMA, fused epilogue) timed with HIP events at C2, C3 and C5 sizes:
+    whole pass (every launch of the call), TFLOP/s = 2*n*m*d / time, fraction of the fp32-MFMA peak."""
+    from mfcd import metrics
+    out = {"peak_TFLOPs": MFMA_F32_PEAK_TF, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "data": "synthetic (Gaussian X, U, V)"}
+    shapes = [("C2", 4096, 4096, 64, 20), ("C3", 16384, 16384, 128, 5), ("C5", 100000, 20000, 256, 3)]
+    g = torch.Generator(device=dev).manual_seed(123)
+    for name, n, m, d, reps in shapes:
+        try:
+            if name == "C2":
+                U, V = U2, V2
+            else:
+                U = torch.randn(n, d, device=dev, generator=g) / d ** 0.5
+                V = torch.randn(m, d, device=dev, generator=g) / d ** 0.5
+            X = torch.empty(n, m, device=dev)
+            for r0 in range(0, n, 8192):                       # generated in slabs: no second n x m temporary
+                X[r0:r0 + 8192].normal_(0.0, 0.5, generator=g)
+            for _ in range(2):
+                metrics.uvt_stats(U, V, X, 1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                rs, sc = metrics.uvt_stats(U, V, X, 1.0)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            tf = 2.0 * n * m * d / (us * 1e-6) / 1e12
+            out[name] = {"n": n, "m": m, "d": d, "pass_us": round(us, 1), "TFLOPs": round(tf, 1),
+                         "frac_of_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+                         "x_read_GBps": round(4.0 * n * m / (us * 1e-6) / 1e9, 1),
+                         "finite": bool(torch.isfinite(sc[:2]).all().item())}
+            del X
+            torch.cuda.empty_cache()
+        except Exception as e:   # a box with less free memory still reports the smaller shapes
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
+def relaunch_multi_gpu(n_gpus):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks ourselves (one process per GPU, RCCL over
+    xGMI), relay rank 0's JSON line and exit with the children's status.  Runs BEFORE this process touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only mode this pool's driver supports
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(proc.stdout)
+        raise SystemExit(proc.returncode or 1)
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
+
+
 def main():
+    ap = build_parser()
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_multi_gpu(args.gpus)
     with _StdoutToStderr():
-        out, is_printer = _run()
+        out, is_printer = _run(args)
     if is_printer:
         print(json.dumps(out), flush=True)
 
 
-def _run():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10490)   # 10 epochs of C2
     ap.add_argument("--warmup", type=int, default=1049)   # 1 epoch
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dp-mode", choices=["native", "allgather", "allreduce"], default=None,
-                    help="form of the data-parallel path (default native: the loop inside libmfcd_hip.so with one RCCL "
-                         "all-gather per step; allgather / allreduce: the per-step torch.distributed loops); given "
-                         "with --gpus 1 it rehearses that path on a one-rank group")
+    ap.add_argument("--no-extras", action="store_true", help="skip the steady_state and uvt records (profiling runs)")
+    ap.add_argument("--steady-epochs", type=int, default=5, help="full epochs of the steady_state record (>= 3)")
+    ap.add_argument("--dp-mode", choices=["native", "allgather", "allreduce", "shard", "selftest"], default=None,
+                    help="form of the multi-GPU path (default native: the loop inside libmfcd_hip.so with one RCCL "
+                         "all-gather per step, global batch 64*R; allgather / allreduce: the per-step torch.distributed "
+                         "loops; shard: row-sharded state, global batch 64, results equal to one GPU; selftest: "
+                         "launcher + rendezvous only, gloo on CPU); given with --gpus 1 it rehearses that path on a "
+                         "one-rank group")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C2",
                     help="C2 (default): the configuration the metric is quoted on; C4: BASELINE.json configs[3], for "
                          "rehearsing the data-parallel path at the size it is named for")
     ap.add_argument("--seed", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="experiment knob of include/mfcd.h (mfcd_set_tuning), e.g. --tune resident_lookahead=8; "
+                         "tools/ sweeps only, every published number uses the defaults")
+    ap.add_argument("--train-path", choices=["auto", "streaming", "resident", "local"], default="auto")
+    return ap
 
+
+def _run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.gpus != world and args.gpus > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values (or without "
+                         "torch.distributed.run: bench.py starts the ranks itself)")
     cfg = dict(WORKLOADS[args.workload])
     cfg["name"] = args.workload
+
+    if args.dp_mode == "selftest":   # launcher + rendezvous check without a GPU (tests/test_dist_cpu.py)
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+        return {"metric": "launcher-selftest", "n_gpus": world, "sum_of_ranks_plus_one": float(t.item())}, rank == 0
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
     if world > 1 or args.dp_mode:
         import torch.distributed as dist
@@ -259,6 +407,10 @@ def _run():
         dist.destroy_process_group()
         return out, rank == 0
 
+    from mfcd import engine
+    if args.tune:
+        engine.set_tuning(**{k: int(v) for k, v in (kv.split("=", 1) for kv in args.tune)})
+    engine.set_train_path(args.train_path)
     runner = Runner(cfg, dev, args.seed)
     runner.run(args.warmup)
     torch.cuda.synchronize()
@@ -266,24 +418,14 @@ def _run():
     consumed = runner.run(args.steps, record=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    runner.engine.check_status()   # a resident launch that gave up on a bounded wait would invalidate the number
+    engine.check_status()   # a resident launch that gave up on a bounded wait would invalidate the number
 
-    from mfcd import _lib
-    plan_resident = (cfg["d"] & (cfg["d"] - 1)) == 0 and 2 <= cfg["d"] <= 256 and (cfg["n"] + cfg["m"]) * cfg["d"] <= 2097152
-    kernel_name = ("resident_train_kernel<D=64,Q=2,LOOK=4,fast> (persistent: one launch per epoch; figures are per optimiser "
-                   "step = launch time / steps)") if plan_resident else "train_step_kernel (one launch per optimiser step)"
     launches = sum(k for _, _, k in runner.train_events)
     train_ms = sum(a.elapsed_time(b) for a, b, _ in runner.train_events)
-    period_us = train_ms * 1e3 / max(launches, 1)          # launch-to-launch, gaps included
-    kavg, kmin, kmax = runner.kernel_sample()
-    abytes = algorithmic_bytes_per_step(cfg)
-    achieved = abytes / (period_us * 1e-6) / 1e9
-    traffic = None   # HBM bytes per optimiser step from rocprofv3 --pmc passes of this same command (profiles/)
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get("hbm_bytes_per_step")
-    except Exception:
-        pass
+    period_us = train_ms * 1e3 / max(launches, 1)          # HIP events around the fused-step calls, gaps included
+    # the form the timed calls took: the longest call of the timed region decides what the record describes
+    longest = max((k for _, _, k in runner.train_events), default=args.steps)
+    plan = engine.train_plan(min(longest * cfg["B"], runner.train.N), cfg["B"], cfg["n"], cfg["m"], cfg["d"])
     out = {
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 6),
@@ -291,13 +433,31 @@ def _run():
         "config": {"workload": f"{cfg['name']}: n={cfg['n']} m={cfg['m']} d={cfg['d']} p={cfg['p']} K={cfg['K']} random triplets, "
                                f"B={cfg['B']}, Adam lr=1e-3 wd=1e-5, {runner.steps_per_epoch} steps/epoch + validation "
                                "pass per epoch", "global_batch": cfg["B"],
-                   "train_samples": runner.train.N, "parallelism": "single"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": abytes, "launch_period_us": round(period_us, 3),
-                     "kernel_us_event_pairs": {"avg": round(kavg, 3), "min": round(kmin, 3), "max": round(kmax, 3)},
-                     "kernel": kernel_name},
+                   "train_samples": runner.train.N, "parallelism": "single", "step_form": plan["form_name"]},
+        "roofline": roofline_record(cfg, plan, period_us),
     }
+    if not args.no_extras:
+        # ---- steady state: whole epochs in this same process (what a training run sees; --steps may be far shorter) ----
+        E = max(3, args.steady_epochs)
+        runner.run(runner.steps_per_epoch - runner.pos if runner.stream is not None else 0)   # finish the open epoch
+        runner.run(runner.steps_per_epoch)                                                     # one untimed epoch
+        torch.cuda.synchronize()
+        runner.reset_events()
+        t1 = time.perf_counter()
+        got = runner.run(E * runner.steps_per_epoch, record=True)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        engine.check_status()
+        k_all = sum(k for _, _, k in runner.train_events)
+        ev_us = sum(a.elapsed_time(b) for a, b, _ in runner.train_events) * 1e3 / max(k_all, 1)
+        splan = engine.train_plan(runner.train.N, cfg["B"], cfg["n"], cfg["m"], cfg["d"])
+        kavg, kmin, kmax = runner.kernel_sample(launches=min(512, runner.steps_per_epoch))
+        out["steady_state"] = {
+            "epochs": E, "steps": E * runner.steps_per_epoch, "value": round(got / dts, 1), "unit": "triplet-updates/s",
+            "us_per_step_wall": round(dts * 1e6 / (E * runner.steps_per_epoch), 4),
+            "us_per_step_events": round(ev_us, 4), "includes": "per-epoch shuffle, prologue, validation pass",
+            "step_form": splan["form_name"], "roofline": roofline_record(cfg, splan, ev_us, (kavg, kmin, kmax))}
+        out["uvt"] = uvt_record(dev, runner.model.U.data, runner.model.V.data)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.seed)
     return out, True

@@ -14,7 +14,8 @@
  *  - every entry returns 0 on success, a positive hipError_t, or a negative MFCD_E* code;
  *    mfcd_error_string() renders either;
  *  - all work is enqueued on `stream` (a hipStream_t, may be NULL = default stream); no entry
- *    synchronises the host with the device;
+ *    synchronises the host with the device except where its comment says so (mfcd_train_steps_timed;
+ *    the bounded run-ahead of mfcd_train_steps);
  *  - factor tables are row-major contiguous fp32: U [n][d], V [m][d];
  *  - a sample is the 16-byte record mfcd_sample {int32 u, i, j; float z} (reference batch tuple
  *    (u, i, j, z), structure.py:527-531, with the label already cast to fp32 as at 849);
@@ -30,13 +31,15 @@
 extern "C" {
 #endif
 
-#define MFCD_ABI_VERSION 1
+#define MFCD_ABI_VERSION 2
 
 #define MFCD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, d out of range)   */
 #define MFCD_EWORKSPACE (-2) /* workspace smaller than mfcd_*_workspace_bytes says             */
 #define MFCD_EALIGN (-3)   /* a table pointer is not 4-byte aligned                            */
 #define MFCD_EINDEX (-4)   /* a sample indexes outside [0,n) x [0,m)^2 (mfcd_check_samples)     */
 #define MFCD_ERCCL (-5)    /* RCCL is not loadable in this process, or an RCCL call failed      */
+#define MFCD_ESTATE (-6)   /* the workspace was not initialised (mfcd_train_workspace_init) or was
+                              planned for other n, m, d                                         */
 
 #define MFCD_MAX_D 1024
 
@@ -71,29 +74,45 @@ int mfcd_eval_batches(const float *U, const float *V, const mfcd_sample *samples
                       float *p_out, void *stream);
 
 /*
- * Bytes of device workspace mfcd_train_steps needs for these sizes.  The first 4 bytes of the
- * workspace are an int32 status word written by the call: 0 = ok, 1 = a bounded in-kernel wait
- * expired (resident form only; U, V, m, v are then undefined).  Read it after the stream has drained.
+ * Workspace of mfcd_train_steps: caller-owned device memory, PLANNED once for a capacity and then reused by every
+ * call that fits it (no per-call re-initialisation, no per-call allocation):
+ *
+ *   bytes = mfcd_train_workspace_bytes(N_cap, B, n, m, d)       N_cap = most samples one call will pass (an epoch)
+ *   mfcd_train_workspace_init(ws, bytes, N_cap, B, n, m, d, stream)
+ *        once after allocating it (256-byte aligned), and again after a reported abort; zero-fills it on `stream`
+ *        and registers the host-side state that belongs to it (pinned staging ring, launch counter).  One workspace
+ *        serves one model on one stream and is driven by one host thread at a time; use one per model / stream.
+ *   mfcd_train_steps(..., ws, bytes, stream)                    any N <= N_cap with ceil(N/B) <= ceil(N_cap/B_plan),
+ *        the same n, m, d; MFCD_ESTATE for an unregistered workspace or other n, m, d, MFCD_EWORKSPACE past the capacity
+ *   mfcd_train_workspace_release(ws)                            before freeing it
+ *
+ * The first 4 bytes are an int32 status word: 0 = ok, 1 = a bounded in-kernel wait of the resident form expired
+ * (U, V, m, v are then undefined).  It is STICKY: no call clears it, so an abort in any earlier call is still
+ * visible when the host finally looks (after the stream has drained); only mfcd_train_workspace_init resets it.
  */
-size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d);
+size_t mfcd_train_workspace_bytes(int64_t N_cap, int B, int n, int m, int d);
+int mfcd_train_workspace_init(void *workspace, size_t workspace_bytes, int64_t N_cap, int B, int n, int m,
+                              int d, void *stream);
+int mfcd_train_workspace_release(void *workspace);
 
 /*
  * Which form of the fused step mfcd_train_steps uses (process-wide):
- *   0 auto (default)  resident when it applies, else streaming
+ *   0 auto (default)  local where it applies; else resident where it applies and the call has at least
+ *                     MFCD_TUNE_SHORT_CALL_STEPS (3) steps; else streaming
  *   1 streaming       one launch per optimiser step, state streamed through HBM (any size, any d)
  *   2 resident        one persistent launch per call, p/m/v held in registers, rows exchanged through
- *                     tagged 8-byte granules; needs d a power of two <= 256 and 12*(n+m)*d bytes of
- *                     state to fit the register files; MFCD_EINVAL from mfcd_train_steps otherwise
- *   3 local           tiny problems ((n+m)*d <= 16384, B <= 4096, any d): one persistent launch of ONE
- *                     workgroup, parameters in LDS, moments in registers, three barriers per step;
- *                     MFCD_EINVAL otherwise.  Measured no faster than the resident form (one CU's ALU and
- *                     the serial per-row accumulation bound it), so "auto" does not select it.
- * Both forms compute the same step (same summation order per row); results agree to fp32 rounding.
+ *                     tagged 8-byte granules; needs d a power of two <= 256, 12*(n+m)*d bytes of state that
+ *                     fit the register files, and every wave of the grid resident at once (asked of the
+ *                     runtime's occupancy query per instantiation); MFCD_EINVAL from mfcd_train_steps otherwise
+ *   3 local           tiny problems ((n+m)*d <= 8192, B <= 4096, any d): one persistent launch of ONE
+ *                     workgroup, parameters in LDS, moments in registers, workgroup barriers only;
+ *                     1.2-5.7x faster than the resident form wherever it applies; MFCD_EINVAL otherwise
+ * All forms compute the same step (same summation order per row); results agree to fp32 rounding.
  */
 int mfcd_set_train_path(int mode);
 
 /*
- * Arithmetic flavour of Adam inside the RESIDENT form, where the step is bound by vector-ALU cycles
+ * Arithmetic flavour of Adam inside the RESIDENT and LOCAL forms, where the step is bound by vector-ALU cycles
  * (process-wide; the streaming form is HBM-bound and always uses the IEEE flavour):
  *   1 fast (default)  same operation order, but sqrt is the hardware v_sqrt_f32 (<= 1 ulp) and the two
  *                     divisions are reciprocal-multiply with one Newton correction (<= 1 ulp) instead of
@@ -104,6 +123,37 @@ int mfcd_set_train_path(int mode);
 int mfcd_set_resident_math(int fast);
 
 /*
+ * Tuning knobs for experiments and tests (process-wide; the defaults are the measured best and what every
+ * published number uses).  They replace the environment variables the round-1 build read on every launch.
+ */
+#define MFCD_TUNE_RESIDENT_Q 1          /* 0 = smallest slice that fits (default); 1, 2, 4, 16 force it          */
+#define MFCD_TUNE_RESIDENT_WPC 2        /* waves per CU for slices of <= 2 registers: 16 (default) or 8        */
+#define MFCD_TUNE_RESIDENT_LOOKAHEAD 3  /* -1 auto (default), 0 off, 4, 8                                      */
+#define MFCD_TUNE_RESIDENT_LDS_PAD 4    /* unused dynamic LDS per workgroup, bytes (default 0)                 */
+#define MFCD_TUNE_RESIDENT_SPIN_LIMIT 5 /* polls before a wave gives up; 0 = default (2^22)                    */
+#define MFCD_TUNE_SHORT_CALL_STEPS 6    /* "auto": calls of fewer steps stream instead (default 3)             */
+int mfcd_set_tuning(int key, int64_t value);
+
+/*
+ * What mfcd_train_steps would do for a call of these sizes under the current settings (no launch; for
+ * benchmarks and logs, so that they do not re-derive the plan).
+ */
+typedef struct mfcd_train_plan {
+    int32_t form;                 /* 1 streaming, 2 resident, 3 local */
+    int32_t resident_q;           /* registers per array and lane (slice = 64*q elements)        */
+    int32_t resident_waves;       /* owner waves = slices                                         */
+    int32_t resident_blocks;      /* workgroups of 4 waves                                        */
+    int32_t resident_lookahead;   /* 0, 4 or 8                                                    */
+    int32_t fast_math;            /* resident / local: Adam flavour                               */
+    int32_t streaming_vec;        /* floats per lane and access (4 unless d % 4 != 0)             */
+    int32_t streaming_chunks;
+    int32_t streaming_blocks;     /* workgroups per step launch                                   */
+    int32_t device_cus;
+    int32_t reserved[6];
+} mfcd_train_plan;
+int mfcd_train_plan_query(int64_t N, int B, int n, int m, int d, int bf16_factors, mfcd_train_plan *out);
+
+/*
  * Runs ceil(N/B) sequential optimiser steps on the device, consuming `samples` in order in
  * batches of B (last one short, divisor = actual batch size).  One step replaces
  * structure.py:847-851: zero_grad, forward, BCE(mean), backward (gather + scatter-add of row
@@ -112,7 +162,8 @@ int mfcd_set_resident_math(int fast);
  *   U,V,mU,vU,mV,vV  parameters and Adam moments (exp_avg, exp_avg_sq), updated in place
  *   step0            optimiser steps already taken (Adam's `step` before this call)
  *   loss_per_step[k] fp32 batch-mean BCE of step k (structure.py:852 loss.item())
- * No dense gradient is materialised and there is no host synchronisation.
+ * No dense gradient is materialised.  The host is never made to wait for the device, with one bound: a workspace's
+ * fifth queued call waits until its first has started (the pinned staging ring of per-step scalars has four slots).
  */
 int mfcd_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
                      const mfcd_sample *samples, int64_t N, int B, int64_t step0, int n, int m,
@@ -159,7 +210,8 @@ int mfcd_batch_coefficients(const float *U, const float *V, const mfcd_sample *s
  * One dense Adam step given per-sample coefficients for a (global) batch of B samples:
  * applies  dU[u]+=g(V[i]-V[j]), dV[i]+=gU[u], dV[j]-=gU[u]  in batch order on top of the
  * weight-decay gradient and updates U,V,m,v in place (structure.py:850-851).
- * `step` is Adam's 1-based step number.  workspace: mfcd_train_workspace_bytes(B,B,n,m,d).
+ * `step` is Adam's 1-based step number.  workspace: mfcd_train_workspace_bytes(B,B,n,m,d) bytes of scratch
+ * (no initialisation needed: this entry keeps no state in it).
  */
 int mfcd_apply_step(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
                     const mfcd_sample *samples, const float *g, int B, int64_t step, int n, int m,

@@ -11,6 +11,7 @@ extern "C" const char *mfcd_error_string(int code)
         case MFCD_EWORKSPACE: return "mfcd: workspace too small";
         case MFCD_EALIGN: return "mfcd: table pointer not 4-byte aligned";
         case MFCD_EINDEX: return "mfcd: sample index out of range";
+        case MFCD_ESTATE: return "mfcd: workspace not initialised for these sizes (mfcd_train_workspace_init)";
         case MFCD_ERCCL: return "mfcd: RCCL is not loadable in this process or an RCCL call failed";
         default: break;
     }

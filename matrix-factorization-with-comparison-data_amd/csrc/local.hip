@@ -268,8 +268,12 @@ size_t local_lds_bytes(int B, int n, int m, int d, LocalArgs *a)
 template <int QL, bool FAST, int RS>
 int launch_local_inst(const LocalArgs &a, size_t lds_bytes, hipStream_t st)
 {
-    MFCD_HIP_TRY(hipFuncSetAttribute((const void *)local_train_kernel<QL, FAST, RS>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    static size_t allowed = 0;   // per instantiation: raise the dynamic-LDS limit only when a launch needs more
+    if (lds_bytes > allowed) {
+        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)local_train_kernel<QL, FAST, RS>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        allowed = lds_bytes;
+    }
     hipLaunchKernelGGL((local_train_kernel<QL, FAST, RS>), dim3(1), dim3(kLocalThreads), lds_bytes, st, a);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;

@@ -30,7 +30,45 @@ bool launch_q(const mfcd_detail::ResidentArgs &a, int blocks, hipStream_t st)
     }
 }
 
+// workgroups per CU the runtime admits for the instantiation the launch above would pick (0: query failed)
+template <int D, int Q>
+int occupancy_q(int look, int fast, int lds_pad)
+{
+    if constexpr ((64 * Q) % D == 0) {
+        int nb = 0;
+        hipError_t e;
+#define MFCD_OCC(L, F)                                                                                         \
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfcd_detail::resident_train_kernel<D, Q, L, F>, 256, \
+                                                     (size_t)lds_pad)
+        if (look >= 8 && fast) MFCD_OCC(8, true);
+        else if (look >= 8) MFCD_OCC(8, false);
+        else if (look > 0 && fast) MFCD_OCC(4, true);
+        else if (look > 0) MFCD_OCC(4, false);
+        else if (fast) MFCD_OCC(0, true);
+        else MFCD_OCC(0, false);
+#undef MFCD_OCC
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        return nb;
+    } else {
+        return 0;
+    }
+}
+
 }  // namespace
+
+extern "C" int MFCD_CAT(mfcd_resident_occupancy_d, MFCD_RES_D)(int Q, int look, int fast, int lds_pad)
+{
+    switch (Q) {
+        case 1: return occupancy_q<MFCD_RES_D, 1>(look, fast, lds_pad);
+        case 2: return occupancy_q<MFCD_RES_D, 2>(look, fast, lds_pad);
+        case 4: return occupancy_q<MFCD_RES_D, 4>(look, fast, lds_pad);
+        case 16: return occupancy_q<MFCD_RES_D, 16>(look, fast, lds_pad);
+        default: return 0;
+    }
+}
 
 extern "C" int MFCD_CAT(mfcd_resident_launch_d, MFCD_RES_D)(const mfcd_detail::ResidentArgs *a, int Q, int blocks,
                                                            void *stream)

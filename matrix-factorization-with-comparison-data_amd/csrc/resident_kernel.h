@@ -7,7 +7,6 @@ namespace mfcd_detail {
 
 typedef unsigned long long u64;
 
-constexpr unsigned kSpinLimit = 1u << 22;  // polls before a wave gives up (~seconds); sets status = 1
 
 __device__ __forceinline__ u64 pack_granule(unsigned tag, float v)
 {
@@ -29,10 +28,10 @@ __device__ __forceinline__ void store_granule(u64 *p, unsigned tag, float v)
 // the hits of the others and set the pace (measured: the same state size split 2731 users / 5461 items, where all rows
 // are touched equally often, ran 12 % faster than 4096 / 4096).  The virtual order therefore INTERLEAVES the two tables
 // over their common length c = min(n, m): user r -> 2r, item r -> 2r + 1 (r < c); the rest of the longer table follows.
-// This static order is the FALLBACK; when the table is small enough the order is rebuilt for every launch from the
-// launch's own touch counts (resident.hip: resident_order_kernel) so that every wave carries the same number of hits.
-// Either way the kernel only sees virtual row ids: the samples are translated once per launch, and the slice load /
-// store goes through the inverse table.
+// The order is closed-form in both directions, so no table is kept: the prologue kernel translates the call's samples
+// to virtual row ids with vrow_u / vrow_v, and the slice load / store of the step kernel maps back with is_item /
+// table_row.  (A per-launch order rebuilt from the launch's own touch counts was measured in round 1 and dropped: the
+// kernel ran within 1 % of this static order.)
 struct RowMap {
     int n, m, c;   // c = min(n, m)
     __host__ __device__ int vrow_u(int u) const { return u < c ? 2 * u : 2 * c + (u - c); }
@@ -77,20 +76,23 @@ __host__ __device__ inline RowMap make_row_map(int n, int m)
 // every step).
 struct ResidentCold {
     float *U, *V, *mU, *vU, *mV, *vV;
-    unsigned long long pad[2];
+    int *status;                     // 0 = ok, 1 = a bounded spin expired (sticky: never cleared by a launch)
+    unsigned long long spin_limit;   // polls before a wave gives up
+    unsigned *touch;                 // [strings][KW]: bit s of a string = "batch s touches a row of that string" (look-
+                                     // ahead form); all-zero between launches: every wave clears its own strings
+    long long KW;                    // dwords per string (covers K + 64 steps; bits past K are zero)
+    unsigned long long pad[6];       // 128 bytes
 };
+static_assert(sizeof(ResidentCold) == 128, "train.hip fills this block as sixteen 8-byte words (kColdBytes)");
 
 struct ResidentArgs {
     const ResidentCold *cold;
     const mfcd_sample *samples;   // the call's samples with u, i, j already translated to VIRTUAL row ids
     const StepScalars *sc;   // [K]
-    u64 *mailbox;            // [N][3][D] granules, zero-filled before the launch
+    u64 *mailbox;            // [N][3][D] granules; a granule is valid when its tag == tag_base + step + 1
     float *loss_terms;       // [N]
-    int *status;             // 0 = ok, 1 = a bounded spin expired
     u64 *dbg;                // [NW][8] cycle accounting (diagnostic build only)
-    const int *inv;          // [n+m] virtual row -> (item ? 0x80000000 : 0) | row inside U / V   (resident_order_kernel)
-    const unsigned *touch;   // [NW][KW] bit s of wave w's string = "batch s touches a row of wave w" (look-ahead form)
-    int KW;                  // dwords per wave in `touch` (covers K + 64 steps; bits past K are zero)
+    unsigned tag_base;       // launch id << 21 (train.hip): granules left behind by earlier launches never match
     int64_t N;
     int B, n, m, K, NW;
     int lookahead;           // 0: publish right before use (any B); >0: look-ahead form (B <= 64)
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
     const int Rhi = (int)(eend / D);  // my rows are VIRTUAL row ids [Rlo, Rhi)
     const int lcol = lane & (D - 1);  // column of my lane when D < 64
     // element e of the virtual table -> table and address offset inside U or V (kernel start and end only)
-    auto elem_is_item = [&](int64_t e) { return a.inv[e / D] < 0; };
-    auto elem_offset = [&](int64_t e) { return (int64_t)(a.inv[e / D] & 0x7fffffff) * D + (e % D); };
+    auto elem_is_item = [&](int64_t e) { return make_row_map(a.n, a.m).is_item((int)(e / D)); };
+    auto elem_offset = [&](int64_t e) { return (int64_t)make_row_map(a.n, a.m).table_row((int)(e / D)) * D + (e % D); };
 
     // ---- load my slice of the state into registers ----
     float p[Q], m1[Q], m2[Q], gr[Q];
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             }
         }
         // rows owned by other waves: poll their granules until every tag is this step's
-        unsigned spins = 0;
+        unsigned spins = 0, limit = 0;
         [[maybe_unused]] const u64 t_poll0 = STAMP();
         while (true) {
             bool ok = true;
@@ -246,11 +248,14 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                 }
             }
             if (__all(ok)) break;
+            if (spins == 0) limit = (unsigned)a.cold->spin_limit;   // first failed poll: the limit lives behind the cold pointer
             ++spins;
-            if (spins > kSpinLimit ||
-                ((spins & 255u) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
+            if (spins > limit || (spins & 255u) == 0) {   // rare
+                int *const status = a.cold->status;
+                if (spins > limit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    if (lane == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
             }
         }
         [[maybe_unused]] const u64 t_poll1 = STAMP();
@@ -356,9 +361,10 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         const int gws = __builtin_amdgcn_readfirstlane(gw);
         const unsigned *tw[NWIN];
         u64 winR[NWIN];
+        const int KW0 = (int)a.cold->KW;
 #pragma unroll
         for (int r = 0; r < NWIN; ++r) {
-            tw[r] = a.touch + (size_t)(ROWWIN ? gws * RPW + r : gws) * a.KW;
+            tw[r] = a.cold->touch + (size_t)(ROWWIN ? gws * RPW + r : gws) * KW0;
             winR[r] = (u64)tw[r][0] << 1;           // j = -1: "batch -1" is empty
         }
         u64 win = winR[0];                          // any of my rows
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                                 adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b2]);
                         }
                         const u64 mr[3] = {(u64)__ballot(rk.u == R), (u64)__ballot(rk.i == R), (u64)__ballot(rk.j == R)};
-                        const unsigned tag = (unsigned)k + 1u;
+                        const unsigned tag = a.tag_base + (unsigned)k + 1u;
 #pragma unroll
                         for (int role = 0; role < 3; ++role) {
                             u64 pm = mr[role];
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                                 adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b2]);
                         }
                         u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + r) * D;
-                        const unsigned tag = (unsigned)k + 1u;
+                        const unsigned tag = a.tag_base + (unsigned)k + 1u;
 #if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
                         if (lane == 0)   // publish time (100 MHz real-time clock), behind the mailbox
                             __hip_atomic_store(a.mailbox + (int64_t)a.N * 3 * D + ((int64_t)k * a.B + tl) * 3 + r,
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     // the abort decision is wave-uniform; saying so keeps the step loop free of exec-mask bookkeeping
-                    const bool ok = process_hit(lane_sample(rk, tl), M0, tl, pos0 + tl, (unsigned)k + 1u, inv_batch);
+                    const bool ok = process_hit(lane_sample(rk, tl), M0, tl, pos0 + tl, a.tag_base + (unsigned)k + 1u, inv_batch);
                     if (__builtin_amdgcn_readfirstlane((int)!ok)) return;
                 }
 #if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
@@ -601,6 +607,17 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #endif
             sc_cur = sc_next;
         }
+        // my touch strings are read by nobody else: leave them all-zero for the next launch's prologue (atomicOr).
+        // Their address is re-derived from fresh scalar loads so that nothing stays live across the step loop for it.
+        {
+            const ResidentCold *cz = a.cold;
+            asm volatile("" : "+s"(cz));
+            unsigned *const tz = cz->touch;
+            const int KWz = (int)cz->KW;
+#pragma unroll
+            for (int r = 0; r < NWIN; ++r)
+                for (int w = lane; w < KWz; w += MFCD_WAVE) tz[(size_t)(ROWWIN ? gws * RPW + r : gws) * KWz + w] = 0u;
+        }
     } else {
         // ================= any B: chunked scan, publish after the whole slice is updated =================
         auto publish = [&](int step) {
@@ -614,9 +631,9 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     const int64_t slot0 = (pos0 + base + tl) * 3;
-                    if ((M.mu >> tl) & 1ull) store_row(__shfl(s.u, tl, MFCD_WAVE), slot0 + 0, (unsigned)step + 1u);
-                    if ((M.mi >> tl) & 1ull) store_row(__shfl(s.i, tl, MFCD_WAVE), slot0 + 1, (unsigned)step + 1u);
-                    if ((M.mj >> tl) & 1ull) store_row(__shfl(s.j, tl, MFCD_WAVE), slot0 + 2, (unsigned)step + 1u);
+                    if ((M.mu >> tl) & 1ull) store_row(__shfl(s.u, tl, MFCD_WAVE), slot0 + 0, a.tag_base + (unsigned)step + 1u);
+                    if ((M.mi >> tl) & 1ull) store_row(__shfl(s.i, tl, MFCD_WAVE), slot0 + 1, a.tag_base + (unsigned)step + 1u);
+                    if ((M.mj >> tl) & 1ull) store_row(__shfl(s.j, tl, MFCD_WAVE), slot0 + 2, a.tag_base + (unsigned)step + 1u);
                 }
             }
         };
@@ -640,7 +657,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     hs.i = __shfl(s.i, tl, MFCD_WAVE);
                     hs.j = __shfl(s.j, tl, MFCD_WAVE);
                     hs.z = __shfl(s.z, tl, MFCD_WAVE);
-                    const bool ok = process_hit(hs, M, tl, pos0 + base + tl, (unsigned)k + 1u, inv_batch);
+                    const bool ok = process_hit(hs, M, tl, pos0 + base + tl, a.tag_base + (unsigned)k + 1u, inv_batch);
                     if (__builtin_amdgcn_readfirstlane((int)!ok)) return;
                 }
             }

@@ -16,7 +16,9 @@
 //
 // Roofline: HBM-bound streaming; algorithmic bytes per step = 24*(n+m)*d + 12*B*d + 16*B.
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -394,7 +396,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 namespace {
 
-constexpr size_t kStatusBytes = 256;  // workspace[0..3] = int32 status word of the last resident launch
+constexpr size_t kStatusBytes = 256;  // workspace[0..3] = int32 status word (sticky: set by an aborting resident launch)
 
 int g_train_path = 0;  // 0 auto, 1 streaming, 2 resident, 3 local (mfcd_set_train_path)
 
@@ -406,72 +408,159 @@ int device_cus()
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             cached = cus;
-        else
+        else {
+            (void)hipGetLastError();
             cached = 256;  // MI355X
+        }
     }
     return cached;
 }
 
-struct ResidentLayout {
-    size_t dbg_off, cold_off, sc_off, terms_off, touch_off, mailbox_off, mailbox_bytes, total;
+constexpr size_t kColdBytes = 128;  // ResidentCold (resident_kernel.h), directly in front of the scalar table
+constexpr size_t kDbgBytes = 16 * 256 * 8 * 8;  // [<=4096 waves][8] u64 of the diagnostic build (tools/)
+constexpr size_t kMaxMailboxBytes = (size_t)24 << 30;  // beyond this the resident form is not planned
+constexpr int kTagStepBits = 21;    // granule tag = launch id << 21 | (step + 1)
+constexpr unsigned kMaxLaunchId = (1u << (32 - kTagStepBits)) - 1;
+
+// Fixed carve-up of a registered workspace (mfcd_train_workspace_init), a function of the CAPACITY it was planned for:
+//   status | dbg | stage (ResidentCold + K_cap+1 step scalars) | terms [N_cap] | touch strings (resident; kept all-zero
+//   between launches) | { U_alt, V_alt (streaming) } overlapping { translated samples, mailbox (resident) }
+// Every call with N <= N_cap and ceil(N/B) <= K_cap uses these offsets, so nothing has to be re-initialised per call.
+struct TrainLayout {
+    size_t dbg_off, stage_off, stage_bytes, terms_off, touch_off, touch_bytes;
+    size_t ualt_off, valt_off, xs_off, mailbox_off, mailbox_bytes, total;
+    int64_t K_cap;
+    bool resident;   // the resident regions exist
 };
 
-constexpr size_t kColdBytes = 64;   // ResidentCold: six table pointers + padding, directly in front of the scalar table
-
-constexpr size_t kDbgBytes = 16 * 256 * 8 * 8;  // [<=4096 waves][8] u64 of the diagnostic build (tools/)
-
-ResidentLayout resident_layout(int64_t N, int B, int n, int m, int d)
+// geometric feasibility of the resident form (tuning knobs ignored: the layout must not depend on them)
+bool resident_feasible(int n, int m, int d, int cus)
 {
-    ResidentLayout L;
-    const int64_t K = (N + B - 1) / B;
+    if (d < 2 || d > 256 || (d & (d - 1)) != 0) return false;
+    const int64_t T = (int64_t)(n + m) * d;
+    static const int kQ[4] = {1, 2, 4, 16};
+    for (int Q : kQ) {
+        if ((64 * Q) % d != 0) continue;
+        const int64_t nw = (T + 64 * (int64_t)Q - 1) / (64 * Q);
+        if (nw <= (int64_t)cus * (Q <= 2 ? 16 : 8) && nw <= mfcd_detail::kResidentMaxWaves) return true;
+    }
+    return false;
+}
+
+TrainLayout train_layout(int64_t N_cap, int B, int n, int m, int d)
+{
+    TrainLayout L{};
+    const int64_t Nc = N_cap > 0 ? N_cap : 1;
+    L.K_cap = (Nc + B - 1) / B;
     size_t off = kStatusBytes;
     L.dbg_off = off;
     off += kDbgBytes;
-    L.cold_off = off;
-    L.sc_off = off + kColdBytes;
-    off += align256(kColdBytes + sizeof(StepScalars) * (size_t)(K + 1));   // one pad entry: the kernel reads step k+1
+    L.stage_off = off;
+    L.stage_bytes = kColdBytes + sizeof(StepScalars) * (size_t)(L.K_cap + 1);   // one pad entry: the kernel reads step k+1
+    off += align256(L.stage_bytes);
     L.terms_off = off;
-    off += align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
-    L.touch_off = off;   // aux region of the resident form: row order, translated samples, touch strings (resident.hip)
-    off += d > 0 ? align256(mfcd_detail::resident_aux_bytes(N, n, m, (int)(K < 0x7fffff00 ? K : 0x7fffff00))) : 0;
-    L.mailbox_off = off;
-    L.mailbox_bytes = sizeof(unsigned long long) * (size_t)N * 3 * (size_t)d;
+    off += align256(sizeof(float) * (size_t)Nc);
+    L.mailbox_bytes = sizeof(unsigned long long) * (size_t)Nc * 3 * (size_t)d;
+    L.resident = resident_feasible(n, m, d, device_cus()) && L.mailbox_bytes <= kMaxMailboxBytes &&
+                 L.K_cap < ((int64_t)1 << 31) - 64;
+    L.touch_off = off;
+    L.touch_bytes = L.resident ? mfcd_detail::resident_touch_bytes(L.K_cap) : 0;
+    off += align256(L.touch_bytes);
+    // streaming members of the union
+    size_t a_off = off;
+    L.ualt_off = a_off;
+    a_off += align256(sizeof(float) * (size_t)n * d);
+    L.valt_off = a_off;
+    a_off += align256(sizeof(float) * (size_t)m * d);
+    // resident members of the union
+    size_t b_off = off;
+    L.xs_off = b_off;
+    L.mailbox_off = b_off;
+    if (L.resident) {
+        b_off += align256(sizeof(mfcd_sample) * (size_t)Nc);
+        L.mailbox_off = b_off;
 #ifdef MFCD_STAMPS
-    // diagnostic build: publish timestamps, one u64 per (sample, role), directly behind the mailbox
-    off += align256((L.mailbox_bytes > 0 ? L.mailbox_bytes : 1) + sizeof(unsigned long long) * (size_t)N * 3);
+        // diagnostic build: publish timestamps, one u64 per (sample, role), directly behind the mailbox
+        b_off += align256(L.mailbox_bytes + sizeof(unsigned long long) * (size_t)Nc * 3);
 #else
-    off += align256(L.mailbox_bytes > 0 ? L.mailbox_bytes : 1);
+        b_off += align256(L.mailbox_bytes);
 #endif
-    L.total = off;
+    }
+    L.total = a_off > b_off ? a_off : b_off;
     return L;
 }
 
-size_t streaming_bytes(int64_t N, int n, int m, int d)
+size_t streaming_bytes(int64_t N, int n, int m, int d)   // mfcd_apply_step's own (unregistered) workspace
 {
     return kStatusBytes + align256(sizeof(float) * (size_t)n * d) + align256(sizeof(float) * (size_t)m * d) +
            align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
 }
 
-constexpr size_t kMaxMailboxBytes = (size_t)24 << 30;  // beyond this the streaming form is used
+// ---- registered workspaces: the host-side state that belongs to one caller-owned workspace ----
+// (one per model / stream; replaces the process-wide staging buffer of round 1).  A workspace is driven by one host
+// thread at a time; the registry itself is guarded.
+constexpr int kStageSlots = 4;
 
-bool resident_applies(int64_t N, int B, int n, int m, int d, mfcd_detail::ResidentPlan *out)
-{
-    if (g_train_path == 1 || g_train_path == 3 || N <= 0) return false;
-    const mfcd_detail::ResidentPlan pl = mfcd_detail::plan_resident(n, m, d, device_cus());
-    if (!pl.ok) return false;
-    if (resident_layout(N, B, n, m, d).mailbox_bytes > kMaxMailboxBytes) return false;
-    if (out) *out = pl;
-    return true;
-}
-
-// pinned staging buffer for the per-step scalar table (grow-only, guarded by an event)
-struct Stage {
-    std::mutex mu;
-    void *host = nullptr;
+struct StageSlot {
+    void *host = nullptr;      // pinned
+    void *devview = nullptr;   // the same memory as the device addresses it
     size_t cap = 0;
     hipEvent_t ev = nullptr;
+    bool pending = false;
 };
-Stage g_stage;
+
+struct WsState {
+    size_t bytes = 0;
+    int device = 0;
+    int64_t N_cap = 0;
+    int B = 0, n = 0, m = 0, d = 0;
+    TrainLayout L{};
+    unsigned launch_id = 0;    // resident launches so far (mod kMaxLaunchId): the tag base of the next one
+    StageSlot slot[kStageSlots];
+    unsigned next = 0;
+    ~WsState()
+    {
+        for (auto &s : slot) {
+            if (s.ev) (void)hipEventDestroy(s.ev);
+            if (s.host) (void)hipHostFree(s.host);
+        }
+    }
+};
+
+std::mutex g_ws_mu;
+std::unordered_map<void *, std::unique_ptr<WsState>> g_ws;
+
+WsState *find_ws(void *workspace)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    auto it = g_ws.find(workspace);
+    return it == g_ws.end() ? nullptr : it->second.get();
+}
+
+// A staging slot nobody reads any more, at least `need` bytes.  Blocks only when kStageSlots calls of this workspace
+// are still queued on the device (bounded run-ahead of the host), never behind the previous call.
+int stage_acquire(WsState &S, size_t need, StageSlot **out)
+{
+    StageSlot &s = S.slot[S.next++ % kStageSlots];
+    if (s.pending) {
+        MFCD_HIP_TRY(hipEventSynchronize(s.ev));
+        s.pending = false;
+    }
+    if (!s.ev) MFCD_HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    if (s.cap < need) {
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = nullptr;
+        s.cap = need < 4096 ? 4096 : need;
+        // device-visible and coherent: the prologue kernel reads the slot directly over the host link
+        if (hipHostMalloc(&s.host, s.cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            MFCD_HIP_TRY(hipHostMalloc(&s.host, s.cap, hipHostMallocDefault));
+        }
+        MFCD_HIP_TRY(hipHostGetDevicePointer(&s.devview, s.host, 0));
+    }
+    *out = &s;
+    return 0;
+}
 
 }  // namespace
 
@@ -489,22 +578,115 @@ extern "C" int mfcd_set_resident_math(int fast)
     return 0;
 }
 
+extern "C" int mfcd_set_tuning(int key, int64_t value)
+{
+    mfcd_detail::Tuning &t = mfcd_detail::g_tune;
+    switch (key) {
+        case MFCD_TUNE_RESIDENT_Q:
+            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 16) return MFCD_EINVAL;
+            t.resident_q = (int)value;
+            return 0;
+        case MFCD_TUNE_RESIDENT_WPC:
+            if (value != 8 && value != 16) return MFCD_EINVAL;
+            t.resident_wpc = (int)value;
+            return 0;
+        case MFCD_TUNE_RESIDENT_LOOKAHEAD:
+            if (value != -1 && value != 0 && value != 4 && value != 8) return MFCD_EINVAL;
+            t.lookahead = (int)value;
+            return 0;
+        case MFCD_TUNE_RESIDENT_LDS_PAD:
+            if (value < 0 || value > 160 * 1024) return MFCD_EINVAL;
+            t.lds_pad = (int)value;
+            return 0;
+        case MFCD_TUNE_RESIDENT_SPIN_LIMIT:
+            if (value < 0 || value > 0x7fffffff) return MFCD_EINVAL;
+            t.spin_limit = value == 0 ? mfcd_detail::kSpinLimitDefault : (unsigned)value;
+            return 0;
+        case MFCD_TUNE_SHORT_CALL_STEPS:
+            if (value < 0 || value > 0x7fffffff) return MFCD_EINVAL;
+            t.short_call_steps = (int)value;
+            return 0;
+        default: return MFCD_EINVAL;
+    }
+}
+
 extern "C" size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d)
 {
     if (N < 0 || B <= 0 || n <= 0 || m <= 0 || d <= 0) return 0;
-    size_t need = streaming_bytes(N, n, m, d);
-    if (g_train_path != 1 && mfcd_detail::plan_resident(n, m, d, 256).ok) {
-        const ResidentLayout L = resident_layout(N, B, n, m, d);
-        if (L.mailbox_bytes <= kMaxMailboxBytes && L.total > need) need = L.total;
+    return train_layout(N, B, n, m, d).total;
+}
+
+extern "C" int mfcd_train_workspace_init(void *workspace, size_t workspace_bytes, int64_t N_cap, int B, int n, int m,
+                                         int d, void *stream)
+{
+    if (!workspace || N_cap < 0 || B <= 0 || n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D) return MFCD_EINVAL;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return MFCD_EALIGN;
+    const TrainLayout L = train_layout(N_cap, B, n, m, d);
+    if (workspace_bytes < L.total) return MFCD_EWORKSPACE;
+    // status word, touch strings, mailbox tags: everything a launch polls or ORs into starts from zero, once
+    MFCD_HIP_TRY(hipMemsetAsync(workspace, 0, L.total, (hipStream_t)stream));
+    auto S = std::make_unique<WsState>();
+    S->bytes = workspace_bytes;
+    (void)hipGetDevice(&S->device);
+    S->N_cap = N_cap > 0 ? N_cap : 1;
+    S->B = B; S->n = n; S->m = m; S->d = d;
+    S->L = L;
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    g_ws[workspace] = std::move(S);
+    return 0;
+}
+
+extern "C" int mfcd_train_workspace_release(void *workspace)
+{
+    std::unique_ptr<WsState> dead;
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        auto it = g_ws.find(workspace);
+        if (it == g_ws.end()) return 0;
+        dead = std::move(it->second);
+        g_ws.erase(it);
     }
-    if (mfcd_detail::local_applies(N > 0 ? N : 1, B, n, m, d)) {
-        const ResidentLayout L = resident_layout(N, B, n, m, 0);   // the local form uses the same layout without a mailbox
-        if (L.total > need) need = L.total;
-    }
-    return need;
+    for (auto &s : dead->slot)   // a slot a queued prologue still reads must outlive it
+        if (s.pending) (void)hipEventSynchronize(s.ev);
+    return 0;
 }
 
 namespace {
+
+// form of the fused step a call with these sizes takes under the current settings
+struct FormChoice {
+    int form;   // 1 streaming, 2 resident, 3 local, <0 error
+    mfcd_detail::ResidentPlan rp;
+};
+
+FormChoice choose_form(bool f32, bool resident_planned, int64_t N, int B, int n, int m, int d)
+{
+    FormChoice c{};
+    const int64_t nsteps = (N + B - 1) / B;
+    const bool local_ok = f32 && nsteps <= 0x7fffffff && mfcd_detail::local_applies(N, B, n, m, d);
+    if (g_train_path == 3) {
+        c.form = local_ok ? 3 : MFCD_EINVAL;
+        return c;
+    }
+    if (g_train_path == 0 && local_ok) {   // measured 1.2-5.7x faster than the resident form wherever it applies
+        c.form = 3;
+        return c;
+    }
+    bool resident_ok = false;
+    if (f32 && resident_planned && g_train_path != 1 && N > 0 && nsteps <= 0x7fffffff &&
+        nsteps + 1 < ((int64_t)1 << kTagStepBits)) {
+        c.rp = mfcd_detail::plan_resident(N, B, n, m, d, device_cus());
+        resident_ok = c.rp.ok;
+    }
+    if (g_train_path == 2) {
+        c.form = resident_ok ? 2 : MFCD_EINVAL;
+        return c;
+    }
+    // auto: the persistent launch has a fixed cost (prologue kernel, slice load / store: ~10 us at C2) that a call of
+    // one or two steps does not earn back against one streaming launch per step
+    c.form = (resident_ok && nsteps >= mfcd_detail::g_tune.short_call_steps) ? 2 : 1;
+    return c;
+}
 
 // Shared body of mfcd_train_steps / mfcd_train_steps_timed.  With `timing_us` set, every step launch is
 // bracketed by its own pair of HIP events on the launch stream and the host waits for them at the end.
@@ -518,109 +700,75 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     if (!mU || !vU || !mV || !vV || N < 0 || B <= 0 || step0 < 0) return MFCD_EINVAL;
     if (N == 0) return 0;
     if (!samples || !workspace) return MFCD_EINVAL;
-    if (workspace_bytes < mfcd_train_workspace_bytes(N, B, n, m, d)) return MFCD_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
+    WsState *S = find_ws(workspace);
+    if (!S) return MFCD_ESTATE;   // mfcd_train_workspace_init has not been called on this workspace
     const int64_t nsteps = (N + B - 1) / B;
+    if (n != S->n || m != S->m || d != S->d) return MFCD_ESTATE;
+    if (N > S->N_cap || nsteps > S->L.K_cap || workspace_bytes < S->L.total) return MFCD_EWORKSPACE;
+    const TrainLayout &L = S->L;
+    hipStream_t st = (hipStream_t)stream;
+    char *base = (char *)workspace;
     int *status = (int *)workspace;
-    MFCD_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
 
     constexpr bool kF32 = sizeof(TP) == 4;   // the resident / local forms hold fp32 state; bf16 factors stream
-    // ---- local form: tiny problems, one workgroup with the parameters in LDS (local.hip) ----
-    // measured (profiles/r01_tiny_problem_forms.txt): 1.2-5.7x faster than the resident form wherever it applies
-    // ((n+m)*d <= 8192), so "auto" takes it first
-    const bool local = kF32 && (g_train_path == 3 || g_train_path == 0) && mfcd_detail::local_applies(N, B, n, m, d);
-    if (g_train_path == 3 && !local) return MFCD_EINVAL;
-    if constexpr (kF32) if (local) {
-        if (nsteps > 0x7fffffff) return MFCD_EINVAL;
-        const ResidentLayout L = resident_layout(N, B, n, m, 0);   // status | dbg | cold | scalars | terms (no mailbox)
-        char *base = (char *)workspace;
-        StepScalars *sc_dev = (StepScalars *)(base + L.sc_off);
-        float *terms_l = (float *)(base + L.terms_off);
-        {
-            std::lock_guard<std::mutex> lock(g_stage.mu);
-            if (!g_stage.ev) MFCD_HIP_TRY(hipEventCreateWithFlags(&g_stage.ev, hipEventDisableTiming));
-            else MFCD_HIP_TRY(hipEventSynchronize(g_stage.ev));
-            const size_t need = sizeof(StepScalars) * (size_t)nsteps;
-            if (g_stage.cap < need) {
-                if (g_stage.host) (void)hipHostFree(g_stage.host);
-                g_stage.cap = need * 2;
-                MFCD_HIP_TRY(hipHostMalloc((void **)&g_stage.host, g_stage.cap, 0));
-            }
-            StepScalars *sc_host = (StepScalars *)g_stage.host;
-            for (int64_t k = 0; k < nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
-            MFCD_HIP_TRY(hipMemcpyAsync(sc_dev, g_stage.host, need, hipMemcpyHostToDevice, st));
-            MFCD_HIP_TRY(hipEventRecord(g_stage.ev, st));
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (timing_us) {
-            MFCD_HIP_TRY(hipEventCreate(&e0));
-            MFCD_HIP_TRY(hipEventCreate(&e1));
-            MFCD_HIP_TRY(hipEventRecord(e0, st));
-        }
-        if (int rc = mfcd_detail::launch_local_steps((float *)U, (float *)V, mU, vU, mV, vV, samples, N, B, n, m, d,
-                                                    sc_dev, adam_static(beta1, beta2, eps, weight_decay), terms_l,
-                                                    (int)nsteps, st))
-            return rc;
-        if (timing_us) MFCD_HIP_TRY(hipEventRecord(e1, st));
-        if (loss_per_step) {
-            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms_l, samples, N, B,
-                               loss_per_step);
-            MFCD_HIP_TRY(hipGetLastError());
-        }
-        if (timing_us) {
-            MFCD_HIP_TRY(hipEventSynchronize(e1));
-            float ms = 0.0f;
-            MFCD_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-            timing_us[0] = timing_us[1] = timing_us[2] = ms * 1e3f / (float)nsteps;
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-        }
-        return 0;
-    }
+    const FormChoice fc = choose_form(kF32, L.resident, N, B, n, m, d);
+    if (fc.form < 0) return fc.form;
 
-    mfcd_detail::ResidentPlan rp;
-    const bool resident = kF32 && resident_applies(N, B, n, m, d, &rp);
-    if (g_train_path == 2 && !resident) return MFCD_EINVAL;
-    if constexpr (kF32) if (resident) {
-        // ---- persistent register-resident form: ONE launch for all nsteps (resident.hip) ----
-        if (nsteps > 0x7fffffff) return MFCD_EINVAL;
-        const ResidentLayout L = resident_layout(N, B, n, m, d);
-        char *base = (char *)workspace;
-        StepScalars *sc_dev = (StepScalars *)(base + L.sc_off);
-        float *terms_r = (float *)(base + L.terms_off);
+    if constexpr (kF32) if (fc.form == 2 || fc.form == 3) {
+        // ---- persistent forms: ONE launch for all nsteps (resident.hip / local.hip) behind ONE prologue kernel ----
+        const bool resident = fc.form == 2;
+        StepScalars *sc_dev = (StepScalars *)(base + L.stage_off + kColdBytes);
+        float *terms = (float *)(base + L.terms_off);
+        StageSlot *slot = nullptr;
+        const size_t need = kColdBytes + sizeof(StepScalars) * (size_t)(nsteps + 1);
+        if (int rc = stage_acquire(*S, need, &slot)) return rc;
+        void **cold = (void **)slot->host;   // ResidentCold {U, V, mU, vU, mV, vV, status, spin limit}
+        cold[0] = U; cold[1] = V; cold[2] = mU; cold[3] = vU; cold[4] = mV; cold[5] = vV; cold[6] = status;
+        cold[7] = (void *)(uintptr_t)mfcd_detail::g_tune.spin_limit;
+        cold[8] = base + L.touch_off;
+        cold[9] = (void *)(uintptr_t)mfcd_detail::resident_touch_words(nsteps);
+        for (int k = 10; k < 16; ++k) cold[k] = nullptr;
+        StepScalars *sc_host = (StepScalars *)((char *)slot->host + kColdBytes);
+        for (int64_t k = 0; k <= nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
+
+        mfcd_sample *xs = resident ? (mfcd_sample *)(base + L.xs_off) : nullptr;
+        unsigned *touch = (unsigned *)(base + L.touch_off);
         unsigned long long *mailbox = (unsigned long long *)(base + L.mailbox_off);
-        {
-            std::lock_guard<std::mutex> lock(g_stage.mu);
-            if (!g_stage.ev) MFCD_HIP_TRY(hipEventCreateWithFlags(&g_stage.ev, hipEventDisableTiming));
-            else MFCD_HIP_TRY(hipEventSynchronize(g_stage.ev));  // previous upload has left the buffer
-            const size_t need = kColdBytes + sizeof(StepScalars) * (size_t)(nsteps + 1);
-            if (g_stage.cap < need) {
-                if (g_stage.host) (void)hipHostFree(g_stage.host);
-                g_stage.cap = need * 2;
-                MFCD_HIP_TRY(hipHostMalloc((void **)&g_stage.host, g_stage.cap, 0));
+        unsigned tag_base = 0;
+        if (resident) {
+            if (S->launch_id >= kMaxLaunchId) {   // the launch ids wrap: forget every granule of the past, once
+                MFCD_HIP_TRY(hipMemsetAsync(mailbox, 0, L.mailbox_bytes, st));
+                S->launch_id = 0;
             }
-            void **cold = (void **)g_stage.host;   // {U, V, mU, vU, mV, vV, 0, 0}
-            cold[0] = U; cold[1] = V; cold[2] = mU; cold[3] = vU; cold[4] = mV; cold[5] = vV; cold[6] = cold[7] = nullptr;
-            StepScalars *sc_host = (StepScalars *)((char *)g_stage.host + kColdBytes);
-            for (int64_t k = 0; k <= nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
-            MFCD_HIP_TRY(hipMemcpyAsync(base + L.cold_off, g_stage.host, need, hipMemcpyHostToDevice, st));
-            MFCD_HIP_TRY(hipEventRecord(g_stage.ev, st));
+            tag_base = ++S->launch_id << kTagStepBits;
         }
-        MFCD_HIP_TRY(hipMemsetAsync(mailbox, 0, L.mailbox_bytes, st));
+        const int rpw = resident ? 64 * fc.rp.Q / d : 0;
+        const int want_touch = resident && fc.rp.lookahead > 0;
+        if (int rc = mfcd_detail::launch_train_prologue(slot->devview, base + L.stage_off, need, samples, N, B, n, m, rpw,
+                                                        mfcd_detail::resident_touch_words(nsteps), want_touch, xs, touch,
+                                                        st))
+            return rc;
+        MFCD_HIP_TRY(hipEventRecord(slot->ev, st));
+        slot->pending = true;
+
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing_us) {
             MFCD_HIP_TRY(hipEventCreate(&e0));
             MFCD_HIP_TRY(hipEventCreate(&e1));
             MFCD_HIP_TRY(hipEventRecord(e0, st));
         }
-        if (int rc = mfcd_detail::launch_resident_steps(rp, base + L.cold_off, samples, N, B, n, m, d, sc_dev,
-                                                       adam_static(beta1, beta2, eps, weight_decay), mailbox, terms_r,
-                                                       status, (unsigned long long *)(base + L.dbg_off),
-                                                       (void *)(base + L.touch_off), (int)nsteps, st))
-            return rc;
+        int rc = 0;
+        if (resident)
+            rc = mfcd_detail::launch_resident_steps(fc.rp, base + L.stage_off, xs, N, B, n, m, d, sc_dev,
+                                                    adam_static(beta1, beta2, eps, weight_decay), mailbox, tag_base,
+                                                    terms, (unsigned long long *)(base + L.dbg_off), (int)nsteps, st);
+        else
+            rc = mfcd_detail::launch_local_steps((float *)U, (float *)V, mU, vU, mV, vV, samples, N, B, n, m, d, sc_dev,
+                                                 adam_static(beta1, beta2, eps, weight_decay), terms, (int)nsteps, st);
+        if (rc) return rc;
         if (timing_us) MFCD_HIP_TRY(hipEventRecord(e1, st));
         if (loss_per_step) {
-            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms_r, samples, N, B,
+            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms, samples, N, B,
                                loss_per_step);
             MFCD_HIP_TRY(hipGetLastError());
         }
@@ -636,12 +784,9 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     }
 
     // ---- streaming form: one launch per optimiser step ----
-    char *ws = (char *)workspace + kStatusBytes;
-    TP *Ualt = (TP *)ws;
-    ws += align256(sizeof(float) * (size_t)n * d);
-    TP *Valt = (TP *)ws;
-    ws += align256(sizeof(float) * (size_t)m * d);
-    float *terms = (float *)ws;
+    TP *Ualt = (TP *)(base + L.ualt_off);
+    TP *Valt = (TP *)(base + L.valt_off);
+    float *terms = (float *)(base + L.terms_off);
 
     const void *ptrs[] = {U, V, mU, vU, mV, vV, Ualt, Valt};
     const Plan pl = make_plan(ptrs, 8, n, m, d);
@@ -690,6 +835,33 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
 }
 
 }  // namespace
+
+extern "C" int mfcd_train_plan_query(int64_t N, int B, int n, int m, int d, int bf16_factors, mfcd_train_plan *out)
+{
+    if (!out || N < 0 || B <= 0 || n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D) return MFCD_EINVAL;
+    std::memset(out, 0, sizeof(*out));
+    const TrainLayout L = train_layout(N, B, n, m, d);
+    const FormChoice fc = choose_form(!bf16_factors, L.resident, N > 0 ? N : 1, B, n, m, d);
+    if (fc.form < 0) return fc.form;
+    out->form = fc.form;
+    if (fc.form == 2) {
+        out->resident_q = fc.rp.Q;
+        out->resident_waves = fc.rp.NW;
+        out->resident_blocks = fc.rp.blocks;
+        out->resident_lookahead = fc.rp.lookahead;
+        out->fast_math = fc.rp.fast_math ? 1 : 0;
+    } else if (fc.form == 3) {
+        out->fast_math = mfcd_detail::g_resident_math != 0;
+    } else {
+        const void *none[] = {nullptr};
+        const Plan pl = make_plan(none, 0, n, m, d);   // alignment of real pointers can only lower vec to 1
+        out->streaming_vec = pl.vec;
+        out->streaming_chunks = pl.chunks;
+        out->streaming_blocks = pl.blocksU + pl.blocksV;
+    }
+    out->device_cus = device_cus();
+    return 0;
+}
 
 extern "C" int mfcd_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
                                 const mfcd_sample *samples, int64_t N, int B, int64_t step0, int n, int m, int d,

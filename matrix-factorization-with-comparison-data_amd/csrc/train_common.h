@@ -141,20 +141,42 @@ int launch_local_steps(float *U, float *V, float *mU, float *vU, float *mV, floa
 struct ResidentPlan {
     bool ok;
     int Q, NW, blocks;
+    int lookahead;   // 0, 4 or 8: the instantiation the launch uses
+    bool fast_math;
 };
+
+constexpr unsigned kSpinLimitDefault = 1u << 22;  // polls before a wave gives up (~seconds); sets status = 1
+
+// process-wide tuning knobs (mfcd_set_tuning; experiments and tests only, defaults are the measured best)
+struct Tuning {
+    int resident_q = 0;          // 0 = smallest slice that fits; else force Q
+    int resident_wpc = 16;       // waves per CU bound for Q <= 2
+    int lookahead = -1;          // -1 auto (4, or 0 for tiny tables), 0 off, 4, 8
+    int lds_pad = 0;             // unused dynamic LDS per workgroup (bytes)
+    unsigned spin_limit = kSpinLimitDefault;   // polls before a wave gives up and sets the status word
+    int short_call_steps = 3;    // "auto": calls of fewer steps than this stream (one launch per step) instead of
+                                 // paying the persistent launch's fixed cost
+};
+extern Tuning g_tune;
 
 extern int g_resident_math;
 
-ResidentPlan plan_resident(int n, int m, int d, int num_cus);
+ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus);
+int resident_lookahead(int64_t N, int B, int n, int m);
 
-// cold_dev: device copy of {U, V, mU, vU, mV, vV, pad[2]} (64 bytes), see ResidentCold in resident_kernel.h
-int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev,
-                          const mfcd_sample *samples, int64_t N, int B, int n, int m, int d, const StepScalars *sc_dev,
-                          const AdamStatic &ac, unsigned long long *mailbox, float *loss_terms, int *status,
-                          unsigned long long *dbg, void *aux, int K, hipStream_t st);
-int resident_touch_words(int K);   // dwords per wave of the touch strings for a call of K steps
-// bytes of the aux region launch_resident_steps carves up: row-order tables, translated samples, touch strings
-size_t resident_aux_bytes(int64_t N, int n, int m, int K);
+// One kernel in front of a resident / local launch: pinned staging slot -> workspace, and (xs != nullptr) the
+// translated samples + touch strings of the resident form.
+int launch_train_prologue(const void *stage_host_devview, void *stage_dev, size_t stage_bytes,
+                          const mfcd_sample *samples, int64_t N, int B, int n, int m, int rows_per_wave, int KW,
+                          int want_touch, mfcd_sample *xs, unsigned *touch, hipStream_t st);
+
+// cold_dev: device copy of ResidentCold (resident_kernel.h: table pointers, status word, spin limit, touch strings);
+// xs: the call's samples translated to virtual row ids
+int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev, const mfcd_sample *xs, int64_t N, int B, int n,
+                          int m, int d, const StepScalars *sc_dev, const AdamStatic &ac, unsigned long long *mailbox,
+                          unsigned tag_base, float *loss_terms, unsigned long long *dbg, int K, hipStream_t st);
+int resident_touch_words(int64_t K);    // dwords per string of the touch strings for a call of K steps
+size_t resident_touch_bytes(int64_t K); // bytes of the touch-string region for calls of up to K steps
 constexpr int kResidentMaxWaves = 4096;   // 256 CUs x 16 waves: upper bound of ResidentPlan::NW (workspace sizing)
 
 }  // namespace mfcd_detail

@@ -99,31 +99,91 @@ def choose_items_by_proximity(X, num_triplets, exclude, k=100):
     return list(found)
 
 
+def _x_pair_diff(X, us, ii, jj):
+    """X[u, i] - X[u, j] for index arrays, as float64 numpy.  `X` is a dense [n, m] tensor / array or a
+    FactoredMatrix (below), for which nothing of size n x m is ever formed."""
+    if isinstance(X, FactoredMatrix):
+        return X.pair_diff(us, ii, jj)
+    Xn = X if isinstance(X, np.ndarray) else X.detach().cpu().numpy()
+    return Xn[us, ii].astype(np.float64) - Xn[us, jj].astype(np.float64)
+
+
+class FactoredMatrix:
+    """Ground-truth matrix kept as its factors, X = A @ B.T (A [n, d], B [m, d], fp32 CPU tensors): the form the
+    "base" law has at BASELINE sizes C4 / C5, where the dense matrix would be 16 GiB / 7.5 GiB.  It offers exactly what
+    the samplers and the label generator read from X: its shape, the first rows, single entries."""
+
+    def __init__(self, A, B):
+        self.A, self.B = A.detach().float().cpu().contiguous(), B.detach().float().cpu().contiguous()
+        self.shape = (self.A.shape[0], self.B.shape[0])
+
+    def rows(self, r0, r1):
+        return (self.A[r0:r1] @ self.B.t()).numpy()
+
+    def entries(self, us, ii):
+        A, B = self.A.numpy(), self.B.numpy()
+        return np.einsum("td,td->t", A[us], B[ii]).astype(np.float32)
+
+    def pair_diff(self, us, ii, jj):
+        return self.entries(us, ii).astype(np.float64) - self.entries(us, jj).astype(np.float64)
+
+    def dense(self, device="cpu"):
+        return (self.A.to(device) @ self.B.to(device).t())
+
+
 def choose_items_by_margin(X, num_triplets, exclude, max_attempts=5000_000):
-    """"Close-Call": |X[u,i]-X[u,j]| below an adaptive margin (ref:46-84).  Attempts are drawn in
-    blocks of 500 from an unseeded numpy Generator, capped at `max_attempts`, exactly as specified
-    there; the per-block filtering is vectorised."""
+    """"Close-Call": |X[u,i]-X[u,j]| below an adaptive margin (ref:46-84).  As there: the margin is the mean range
+    of the first ten rows times the sampling density, attempts come in blocks of 500 from an UNSEEDED numpy Generator
+    (so there is no draw order to keep), at most `max_attempts` of them, and a short result is reported, not raised.
+    Many blocks are drawn and filtered per numpy pass (the reference walks every attempt in Python); the attempt
+    counter still advances in blocks of 500 and stops with the block that completes the request."""
     n, m = X.shape
     exclude = exclude or set()
-    head = X[:min(10, n)].cpu().numpy()
+    head = X.rows(0, min(10, n)) if isinstance(X, FactoredMatrix) else X[:min(10, n)].cpu().numpy()
     margin = np.mean(head.max(axis=1) - head.min(axis=1)) * num_triplets / (n * m)
-    Xn = X.cpu().numpy()
+    Xn = X if isinstance(X, FactoredMatrix) else X.cpu().numpy()
     rng = np.random.default_rng()
-    found, attempts, block = set(), 0, 500
-    while len(found) < num_triplets and attempts < max_attempts:
-        us = rng.integers(0, n, size=block)
-        ij = rng.integers(0, m, size=(block, 2))
-        close = (ij[:, 0] != ij[:, 1]) & (np.abs(Xn[us, ij[:, 0]] - Xn[us, ij[:, 1]]) <= margin)
-        for r in np.nonzero(close)[0]:
-            t = (us[r], ij[r, 0], ij[r, 1])
-            if t not in found and t not in exclude:
-                found.add(t)
-                if len(found) >= num_triplets:
-                    break
-        attempts += block
+    enc = lambda u, i, j: (u.astype(np.int64) * m + i) * m + j                   # noqa: E731
+    barred = np.sort(np.fromiter(((u * m + i) * m + j for u, i, j in exclude), dtype=np.int64, count=len(exclude))) \
+        if exclude else None
+    found_keys = np.empty(0, dtype=np.int64)
+    rows, attempts, block = [], 0, 500
+    need = int(num_triplets)
+    while need > 0 and attempts < max_attempts:
+        nblk = max(1, min(400, (max_attempts - attempts + block - 1) // block))   # blocks in this pass
+        us = rng.integers(0, n, size=nblk * block)
+        ij = rng.integers(0, m, size=(nblk * block, 2))
+        ii, jj = ij[:, 0], ij[:, 1]
+        close = ii != jj
+        cand = np.flatnonzero(close)
+        close[cand] = np.abs(_x_pair_diff(Xn, us[cand], ii[cand], jj[cand])) <= margin
+        idx = np.flatnonzero(close)
+        key = enc(us[idx], ii[idx], jj[idx])
+        ok = np.ones(idx.size, dtype=bool)
+        if barred is not None:
+            ok &= ~np.isin(key, barred)
+        if found_keys.size:
+            ok &= ~np.isin(key, found_keys)
+        idx, key = idx[ok], key[ok]
+        _, first = np.unique(key, return_index=True)                              # first attempt of every new triplet
+        first.sort()
+        idx, key = idx[first], key[first]
+        if idx.size >= need:                                                      # the request completes inside this pass
+            idx, key = idx[:need], key[:need]
+            attempts += (int(idx[-1]) // block + 1) * block
+        else:
+            attempts += nblk * block
+        rows.append(np.stack((us[idx], ii[idx], jj[idx]), axis=1))
+        found_keys = np.concatenate((found_keys, key))
+        need -= idx.size
+    got = np.concatenate(rows) if rows else np.empty((0, 3), dtype=np.int64)
+    found = set()
+    for t in zip(got[:, 0].tolist(), got[:, 1].tolist(), got[:, 2].tolist()):
+        found.add(t)
     if len(found) < num_triplets:
+        top = float(np.max(X.A.numpy()) if isinstance(X, FactoredMatrix) else np.max(Xn))
         print(f"⚠️ Only {len(found)} triplets generated (target={num_triplets}, margin={margin:.4f}) "
-              f"after {attempts} attempts.maximum : {np.max(Xn)}")
+              f"after {attempts} attempts.maximum : {top}")
     return list(found)
 
 
@@ -154,10 +214,7 @@ def _popularity_probs(m, method, alpha):
     return w / w.sum()
 
 
-def choose_items_by_popularity(X, num_triplets, exclude, method="zipf", alpha=1.5):
-    """i, j drawn without replacement from an item-popularity law over the item index (ref:103-128)."""
-    n, m = X.shape
-    probs = _popularity_probs(m, method, alpha)
+def _choose_items_by_popularity_serial(n, m, probs, num_triplets, exclude):
     items = np.arange(m)
     found = set()
     while len(found) < num_triplets:
@@ -165,6 +222,97 @@ def choose_items_by_popularity(X, num_triplets, exclude, method="zipf", alpha=1.
         i, j = np.random.choice(items, size=2, replace=False, p=probs).tolist()
         if _accept((u, i, j), i, j, exclude, found):
             found.add((u, i, j))
+    return list(found)
+
+
+def choose_items_by_popularity(X, num_triplets, exclude, method="zipf", alpha=1.5):
+    """i, j drawn without replacement from an item-popularity law over the item index (ref:103-128): per attempt one
+    torch.randint(n) and one numpy `choice(m, size=2, replace=False, p=probs)`.
+
+    The reference pays O(m) per attempt inside `choice` (a cumsum over the catalogue): ~100 s for C5's 500 000
+    triplets.  Here the SAME draws are consumed in bulk.  numpy's legacy choice (mtrand.pyx, replace=False with p)
+    draws two uniforms x0, x1, maps them through cdf = cumsum(p) / cdf[-1] with searchsorted(side='right'); if the two
+    items differ they are (i, j); if they coincide it keeps i, draws ONE more uniform and maps it through the cdf of
+    p with p[i] = 0.  So an attempt consumes 2 or 3 uniforms (two 32-bit Mersenne-Twister words each) and one
+    torch word (w % n).  Blocks of attempts are evaluated with numpy, the walk "position += 2 or 3" is a cheap integer
+    pass, and both generators are then rewound and advanced by exactly what the one-at-a-time loop would have used, so
+    everything drawn afterwards is unchanged.  `list(set)` order is kept (attempt order), as the split depends on it."""
+    n, m = X.shape
+    exclude = exclude or set()
+    probs = _popularity_probs(m, method, alpha)
+    if n >= 2 ** 32 or num_triplets <= 0 or m < 2:
+        return _choose_items_by_popularity_serial(n, m, probs, num_triplets, exclude)
+    cdf = np.cumsum(probs)
+    cdf /= cdf[-1]
+    enc = lambda u, i, j: (u.astype(np.int64) * m + i) * m + j                   # noqa: E731
+    barred = np.sort(np.fromiter(((u * m + i) * m + j for u, i, j in exclude), dtype=np.int64, count=len(exclude))) \
+        if exclude else None
+    t_state, n_state = torch.get_rng_state(), np.random.get_state()
+    rows, found_keys = [], np.empty(0, dtype=np.int64)
+    attempts = uniforms = 0
+    need = int(num_triplets)
+    cdf_without = {}
+    while need > 0:
+        A = max(4096, need + need // 4 + 64)
+        us = torch.randint(0, n, (A,)).numpy()
+        x = np.random.random_sample(3 * A)
+        first = cdf.searchsorted(x, side="right")
+        same = (first[:-1] == first[1:]).tolist()
+        starts = np.empty(A, dtype=np.int64)                                      # position of attempt a's first uniform
+        pos = 0
+        for a in range(A):
+            starts[a] = pos
+            pos += 3 if same[pos] else 2
+        ii = first[starts]
+        jj = first[starts + 1]
+        coll = np.flatnonzero(ii == jj)
+        if coll.size:                                                             # second round of choice(): p[i] = 0
+            extra = x[starts[coll] + 2]
+            for item in np.unique(ii[coll]).tolist():
+                c2 = cdf_without.get(item)
+                if c2 is None:
+                    p2 = probs.copy()
+                    p2[item] = 0
+                    c2 = np.cumsum(p2)
+                    c2 /= c2[-1]
+                    if len(cdf_without) < 512:
+                        cdf_without[item] = c2
+                sel = ii[coll] == item
+                jj[coll[sel]] = c2.searchsorted(extra[sel], side="right")
+        key = enc(us, ii, jj)
+        ok = ii != jj
+        if barred is not None:
+            ok &= ~np.isin(key, barred)
+        if found_keys.size:
+            ok &= ~np.isin(key, found_keys)
+        idx = np.flatnonzero(ok)
+        _, fst = np.unique(key[idx], return_index=True)
+        fst.sort()
+        idx = idx[fst]
+        if idx.size >= need:
+            idx = idx[:need]
+            last = int(idx[-1])
+            attempts += last + 1
+            uniforms += int(starts[last]) + (3 if same[int(starts[last])] else 2)
+        else:
+            attempts += A
+            uniforms += pos
+            # the next block must continue where this one ended in BOTH streams
+            torch.set_rng_state(t_state)
+            np.random.set_state(n_state)
+            torch.randint(0, n, (attempts,))
+            np.random.random_sample(uniforms)
+        rows.append(np.stack((us[idx], ii[idx], jj[idx]), axis=1))
+        found_keys = np.concatenate((found_keys, key[idx]))
+        need -= idx.size
+    torch.set_rng_state(t_state)
+    np.random.set_state(n_state)
+    torch.randint(0, n, (attempts,))                                              # leave both generators where the
+    np.random.random_sample(uniforms)                                             # one-at-a-time loop would
+    got = np.concatenate(rows)
+    found = set()
+    for t in zip(got[:, 0].tolist(), got[:, 1].tolist(), got[:, 2].tolist()):
+        found.add(t)
     return list(found)
 
 

@@ -20,8 +20,12 @@ SIGNATURES = {
     "mfcd_check_samples": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "mfcd_eval_batches": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfcd_train_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
+    "mfcd_train_workspace_init": (_i32, [_vp, _sz, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mfcd_train_workspace_release": (_i32, [_vp]),
     "mfcd_set_train_path": (_i32, [_i32]),
     "mfcd_set_resident_math": (_i32, [_i32]),
+    "mfcd_set_tuning": (_i32, [_i32, _i64]),
+    "mfcd_train_plan_query": (_i32, [_i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mfcd_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp, _sz, _vp]),
     "mfcd_train_steps_bf16": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp, _sz, _vp]),
     "mfcd_eval_batches_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -41,6 +45,18 @@ SIGNATURES = {
     "mfcd_uvt_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_uvt_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
 }
+
+TUNE_KEYS = {"resident_q": 1, "resident_wpc": 2, "resident_lookahead": 3, "resident_lds_pad": 4,
+             "resident_spin_limit": 5, "short_call_steps": 6}
+
+
+class TrainPlan(ctypes.Structure):
+    """mfcd_train_plan of include/mfcd.h."""
+    _fields_ = [(k, ctypes.c_int32) for k in ("form", "resident_q", "resident_waves", "resident_blocks",
+                                               "resident_lookahead", "fast_math", "streaming_vec",
+                                               "streaming_chunks", "streaming_blocks", "device_cus")] + \
+               [("reserved", ctypes.c_int32 * 6)]
+
 
 _lib = None
 
@@ -62,7 +78,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if lib.mfcd_abi_version() != 1:
+        if lib.mfcd_abi_version() != 2:
             raise MfcdError("libmfcd_hip.so ABI version mismatch")
         _lib = lib
     return _lib

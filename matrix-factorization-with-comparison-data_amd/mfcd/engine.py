@@ -142,18 +142,70 @@ class StreamPrefetch:
 
 
 class Workspace:
+    """One PLANNED training workspace (include/mfcd.h: mfcd_train_workspace_init): a device buffer sized for a
+    capacity (most samples per call, batch size, table shape) plus the library-side state registered for it.
+    It is re-planned only when a call does not fit; calls that fit re-initialise nothing."""
+
     def __init__(self):
         self.buf = None
+        self.plan = None       # (N_cap, B, n, m, d)
+        self.k_cap = 0
+        self.retired = []      # replaced buffers whose status word has not been looked at yet
 
-    def get(self, nbytes, device):
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    def fits(self, N, B, n, m, d):
+        if self.buf is None or self.plan[2:] != (n, m, d):
+            return False
+        return N <= self.plan[0] and n_batches(N, B) <= self.k_cap
+
+    def ensure(self, N, B, n, m, d, device):
+        if self.fits(N, B, n, m, d) and self.buf.device == device:
+            return self.buf
+        L = _lib.load()
+        n_cap = max(int(N), 1)
+        if self.plan is not None and self.plan[2:] == (n, m, d):
+            n_cap = max(n_cap, self.plan[0])      # never shrink a plan for the same tables
+        self.drop(keep_for_status=True)
+        nbytes = int(L.mfcd_train_workspace_bytes(n_cap, B, n, m, d))
+        self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _lib.check(L.mfcd_train_workspace_init(_lib.ptr(self.buf), self.buf.numel(), n_cap, B, n, m, d,
+                                               _lib.stream_ptr(device)))
+        self.plan, self.k_cap = (n_cap, B, n, m, d), n_batches(n_cap, B)
         return self.buf
 
+    def drop(self, keep_for_status=False):
+        if self.buf is not None:
+            _lib.check(_lib.load().mfcd_train_workspace_release(_lib.ptr(self.buf)))
+            if keep_for_status:
+                self.retired.append(self.buf[:4])
+        self.buf, self.plan, self.k_cap = None, None, 0
 
-_ws = Workspace()
+    def status(self):
+        """Status words of this workspace and of the buffers it replaced since the last look.  Synchronises."""
+        words = list(self.retired) + ([self.buf[:4]] if self.buf is not None else [])
+        self.retired = []
+        return [int(w.view(torch.int32).item()) for w in words]
+
+
+_workspaces = {}   # (device index, stream handle) -> Workspace: one per device and stream, never shared between them
+
+
+def workspace_for(device):
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lib.stream_ptr(dev))
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _workspaces[key] = Workspace()
+    return ws
+
+
+def reserve_workspace(n_samples, batch_size, n, m, d, device):
+    """Plan the current stream's workspace for calls of up to `n_samples` samples (an epoch) BEFORE the first call, so
+    that a short first call (warm-up, a partial epoch) does not size it too small and force a re-plan later."""
+    return workspace_for(device).ensure(n_samples, batch_size, n, m, d, torch.device(device))
+
 
 TRAIN_PATHS = {"auto": 0, "streaming": 1, "resident": 2, "local": 3}
+FORM_NAMES = {1: "streaming", 2: "resident", 3: "local"}
 
 
 def set_train_path(mode):
@@ -166,13 +218,36 @@ def set_resident_math(flavour):
     _lib.check(_lib.load().mfcd_set_resident_math({"ieee": 0, "fast": 1}[flavour]))
 
 
+def set_tuning(**knobs):
+    """Experiment / test knobs of include/mfcd.h (mfcd_set_tuning), e.g. set_tuning(resident_lookahead=0)."""
+    L = _lib.load()
+    for name, value in knobs.items():
+        _lib.check(L.mfcd_set_tuning(_lib.TUNE_KEYS[name], int(value)))
+
+
+def train_plan(n_samples, batch_size, n, m, d, bf16=False):
+    """What the library would do for a call of these sizes under the current settings → dict (mfcd_train_plan)."""
+    import ctypes
+    out = _lib.TrainPlan()
+    _lib.check(_lib.load().mfcd_train_plan_query(n_samples, batch_size, n, m, d, int(bool(bf16)), ctypes.byref(out)))
+    plan = {k: int(getattr(out, k)) for k, _ in _lib.TrainPlan._fields_ if k != "reserved"}
+    plan["form_name"] = FORM_NAMES[plan["form"]]
+    return plan
+
+
 def check_status():
-    """Raise if the last resident launch gave up on a bounded wait (workspace status word). Synchronises."""
-    if _ws.buf is not None:
-        code = int(_ws.buf[:4].view(torch.int32).item())
-        if code != 0:
-            raise _lib.MfcdError(f"resident training kernel aborted (status {code}): a bounded in-kernel wait expired; "
-                                 "parameters are undefined")
+    """Raise if ANY resident launch since the last check gave up on a bounded wait (the workspace status word is
+    sticky: an abort in an early epoch is still there at the end of the run).  Synchronises.  A workspace that
+    reported an abort is dropped, so the next call plans and zero-fills a fresh one."""
+    bad = None
+    for ws in list(_workspaces.values()):
+        for code in ws.status():
+            if code != 0:
+                bad = code
+                ws.drop()
+    if bad is not None:
+        raise _lib.MfcdError(f"resident training kernel aborted (status {bad}): a bounded in-kernel wait expired; "
+                             "parameters are undefined")
 
 
 def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None):
@@ -188,8 +263,9 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None)
     nsteps = n_batches(N, batch_size)
     if loss_out is None:
         loss_out = torch.empty(max(nsteps, 1), dtype=torch.float32, device=U.device)
-    nbytes = L.mfcd_train_workspace_bytes(N, batch_size, n, m, d)
-    ws = _ws.get(nbytes, U.device)
+    if N == 0:
+        return loss_out[:0]
+    ws = workspace_for(U.device).ensure(N, batch_size, n, m, d, U.device)
     lr, b1, b2, eps, wd = binding.hyper()
     args = [_lib.ptr(U), _lib.ptr(V), _lib.ptr(mU), _lib.ptr(vU), _lib.ptr(mV), _lib.ptr(vV),
             _lib.ptr(samples_dev), N, batch_size, binding.step, n, m, d, lr, b1, b2, eps, wd,
@@ -240,6 +316,8 @@ def fit(model, train_loader, val_loader, optimizer, num_epochs, progress=None):
     n, m = U.shape[0], V.shape[0]
     train = SampleStore.from_loader(train_loader, n, m, dev)
     val = SampleStore.from_loader(val_loader, n, m, dev)
+    if train.N and train_loader.batch_size:
+        reserve_workspace(train.N, train_loader.batch_size, n, m, U.shape[1], dev)
     per_epoch_train, per_epoch_val = [], []
     it = range(num_epochs) if progress is None else progress(range(num_epochs))
     # The host draws the epoch orders in the reference's sequence (train_0, val_0, train_1, val_1, ...: every
@@ -259,7 +337,8 @@ def fit(model, train_loader, val_loader, optimizer, num_epochs, progress=None):
             pre.start(train, order)
         vl, _, _ = eval_batches(U, V, val.ordered(vorder), vbs)
         per_epoch_val.append(vl)
-    # one device->host transfer for the whole run (the reference syncs every step at 852)
+    # one device->host transfer for the whole run (the reference syncs every step at 852); the status word is
+    # sticky, so an abort in ANY epoch surfaces here
     check_status()
     tl = [python_float_sum(t.cpu().numpy()) / max(len(t), 1) for t in per_epoch_train]
     vl = [python_float_sum(t.cpu().numpy()) / max(len(t), 1) for t in per_epoch_val]

@@ -141,9 +141,12 @@ class BTLPreferenceDataset(Dataset):
         if idx.shape[0] == 0:
             return np.empty((0, 4), dtype=np.float64)
         it = torch.from_numpy(idx)
-        Xc = self.X.detach()
-        dev_idx = it.to(Xc.device)
-        diff = (Xc[dev_idx[:, 0], dev_idx[:, 1]] - Xc[dev_idx[:, 0], dev_idx[:, 2]]).to("cpu")
+        if isinstance(self.X, _gd.FactoredMatrix):     # X kept as factors (C4 / C5 sizes): entries on demand, fp32
+            diff = torch.from_numpy(self.X.entries(idx[:, 0], idx[:, 1]) - self.X.entries(idx[:, 0], idx[:, 2]))
+        else:
+            Xc = self.X.detach()
+            dev_idx = it.to(Xc.device)
+            diff = (Xc[dev_idx[:, 0], dev_idx[:, 1]] - Xc[dev_idx[:, 0], dev_idx[:, 2]]).to("cpu")
         score = torch.sigmoid(self.scale * diff)                          # ref:509 (fp32, CPU op as there)
         draws = torch.bernoulli(score.repeat_interleave(K)).view(idx.shape[0], K)
         if self.soft_label and train:                                   # ref:510-513

@@ -19,11 +19,23 @@ def test_library_exports_every_declared_symbol():
     declared.discard("mfcd_sample")
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.load()  # binds each symbol; AttributeError if one is missing
-    assert L.mfcd_abi_version() == 1
+    assert L.mfcd_abi_version() == 2
     assert L.mfcd_error_string(0).decode() == "success"
     assert L.mfcd_error_string(-1).decode().startswith("mfcd:")
     # pure host helpers may be called without a GPU
     assert L.mfcd_train_workspace_bytes(1000, 64, 16, 16, 8) >= 2 * 16 * 8 * 4 + 4000
+    # an unregistered workspace is refused before anything touches the device; tuning setters validate their input
+    assert L.mfcd_set_tuning(_lib.TUNE_KEYS["resident_lookahead"], 5) == -1
+    assert L.mfcd_set_tuning(_lib.TUNE_KEYS["resident_lookahead"], -1) == 0
+    assert L.mfcd_train_workspace_release(None) == 0
+    assert L.mfcd_error_string(-6).decode().startswith("mfcd: workspace not initialised")
+    plan = _lib.TrainPlan()
+    import ctypes
+    assert L.mfcd_train_plan_query(67108, 64, 4096, 4096, 64, 0, ctypes.byref(plan)) == 0
+    assert (plan.form, plan.resident_q, plan.resident_waves, plan.resident_lookahead) == (2, 2, 4096, 4)
+    assert L.mfcd_train_plan_query(64, 64, 4096, 4096, 64, 0, ctypes.byref(plan)) == 0 and plan.form == 1   # short call
+    assert L.mfcd_train_plan_query(67108, 64, 65536, 65536, 64, 0, ctypes.byref(plan)) == 0 and plan.form == 1
+    assert L.mfcd_train_plan_query(1310, 64, 256, 256, 8, 0, ctypes.byref(plan)) == 0 and plan.form == 3
     assert L.mfcd_uvt_workspace_bytes(100, 100, 8) > 0
 
 

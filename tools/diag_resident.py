@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 r = bench.Runner(bench.C2, dev, 0)
 r.run(1049); torch.cuda.synchronize()
 t0 = time.perf_counter(); r.run(1049); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-ws = engine._ws.buf
+ws = engine.workspace_for(dev).buf
 dbg = ws[256:256 + 4096 * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
 dbg = dbg[dbg[:, 0] > 0]
 K = 1049

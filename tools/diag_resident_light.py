@@ -17,7 +17,7 @@ stream = r.train.ordered(order)
 torch.cuda.synchronize()
 e0.record(); engine.train_steps(r.bind, stream, 64); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-ws = engine._ws.buf
+ws = engine.workspace_for(dev).buf
 dbg = ws[256:256 + 4096 * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
 dbg = dbg[dbg[:, 0] > 0]
 K = 1049
