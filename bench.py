@@ -277,6 +277,30 @@ class _StdoutToStderr:
         return False
 
 
+def clock_ramp(runner, seconds):
+    """UNTIMED, before the warm-up steps: keep the chip busy for `seconds` with the same fused-step calls on a SCRATCH
+    copy of the model (the measured model and its optimiser are not touched).  A GPU that has sat idle while the host
+    prepared the inputs answers its first launches at idle clocks and wake-up latency (measured on this pool: the first
+    20-step call after 0.5 s of idling takes 4-5x the time of the fortieth, tools/diag_short_calls.py); a benchmark of
+    --steps 20 would measure that instead of the code.  Returns what was done, for the JSON line."""
+    import copy
+    engine, cfg = runner.engine, runner.cfg
+    scratch = copy.deepcopy(runner.model)
+    opt = torch.optim.Adam(scratch.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
+    bind = engine.AdamBinding(scratch, opt)
+    B = cfg["B"]
+    chunk = runner.train.dev[: 20 * B]
+    t0 = time.perf_counter()
+    calls = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(16):
+            engine.train_steps(bind, chunk, B)
+        calls += 16
+        torch.cuda.synchronize()
+    return {"untimed": True, "seconds": round(time.perf_counter() - t0, 3), "calls": calls,
+            "what": "20-step fused calls on a scratch copy of the model, before the warm-up steps"}
+
+
 def uvt_record(dev, U2, V2):
     """Dense UV^T metric pass (mfcd_uvt_stats: fp32 MFMA, fused epilogue) timed with HIP events at C2, C3 and C5 sizes:
     whole pass (every launch of the call), TFLOP/s = 2*n*m*d / time, fraction of the fp32-MFMA peak."""
@@ -355,6 +379,8 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the steady_state and uvt records (profiling runs)")
     ap.add_argument("--steady-epochs", type=int, default=5, help="full epochs of the steady_state record (>= 3)")
+    ap.add_argument("--clock-ramp", type=float, default=0.3, metavar="SECONDS",
+                    help="untimed busy phase on scratch state before the warm-up steps (0 = none); see clock_ramp()")
     ap.add_argument("--dp-mode", choices=["native", "allgather", "allreduce", "shard", "selftest"], default=None,
                     help="form of the multi-GPU path (default native: the loop inside libmfcd_hip.so with one RCCL "
                          "all-gather per step, global batch 64*R; allgather / allreduce: the per-step torch.distributed "
@@ -412,6 +438,7 @@ def _run(args):
         engine.set_tuning(**{k: int(v) for k, v in (kv.split("=", 1) for kv in args.tune)})
     engine.set_train_path(args.train_path)
     runner = Runner(cfg, dev, args.seed)
+    ramp = clock_ramp(runner, args.clock_ramp) if args.clock_ramp > 0 else None
     runner.run(args.warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -436,6 +463,8 @@ def _run(args):
                    "train_samples": runner.train.N, "parallelism": "single", "step_form": plan["form_name"]},
         "roofline": roofline_record(cfg, plan, period_us),
     }
+    if ramp:
+        out["clock_ramp"] = ramp
     if not args.no_extras:
         # ---- steady state: whole epochs in this same process (what a training run sees; --steps may be far shorter) ----
         E = max(3, args.steady_epochs)

@@ -132,6 +132,7 @@ int mfcd_set_resident_math(int fast);
 #define MFCD_TUNE_RESIDENT_LDS_PAD 4    /* unused dynamic LDS per workgroup, bytes (default 0)                 */
 #define MFCD_TUNE_RESIDENT_SPIN_LIMIT 5 /* polls before a wave gives up; 0 = default (2^22)                    */
 #define MFCD_TUNE_SHORT_CALL_STEPS 6    /* "auto": calls of fewer steps stream instead (default 3)             */
+#define MFCD_TUNE_UVT_WPE128 7          /* waves per SIMD of the d = 128 UV^T kernel: 2 (default) or 3        */
 int mfcd_set_tuning(int key, int64_t value);
 
 /*
@@ -261,6 +262,38 @@ int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, float *mV, flo
                         float *loss_per_step, void *workspace, size_t workspace_bytes, void *comm, void *stream);
 
 /*
+ * Row-sharded training: STRONG scaling with the reference's batch size (structure.py:668, B = 64), results equal to
+ * the single-GPU run.  Rank r of `world` holds rows [lo_r, hi_r) = mfcd_shard_rows(rows, r, world) of U and of V and of
+ * their Adam moments (1/world of the state and of the dense Adam sweep); every rank sees the same sample stream.
+ * Per optimiser step: the ranks write the rows of the batch they own into an exchange buffer xbuf[3][B][d] (role u, i,
+ * j; zeros elsewhere), ONE all-reduce(sum) of that buffer taken as 32-bit integers reproduces every row bit for bit
+ * (exactly one rank contributes non-zero bits per row), then the fused step runs over the shard in place, reading the
+ * samples' rows from the buffer.  Every rank forms every sample's BCE term, so the step losses need no collective.
+ * The arithmetic per element is that of mfcd_train_steps' streaming form: results are bit-identical to it.
+ *
+ *   mfcd_shard_pack / mfcd_shard_apply   the two halves of a step, for a caller that owns the collective
+ *                                        (mfcd/dist.py over torch.distributed: RCCL, or gloo in the CPU tests)
+ *   mfcd_shard_train_steps               the native loop (RCCL bound at run time, communicator from
+ *                                        mfcd_dp_comm_create); table pointers are the rank's SHARDS.
+ *                                        comm == NULL: the pointers are the FULL tables and this process plays every
+ *                                        rank in turn (single-process rehearsal of any world size).
+ * xbuf / workspace: mfcd_shard_workspace_bytes(N, B, d) bytes (the buffer comes first, 3*B*d floats).
+ * u_lo..v_hi are GLOBAL row bounds of the shard; batch records name global rows.
+ */
+int mfcd_shard_rows(int rows, int rank, int world, int *lo, int *hi);
+size_t mfcd_shard_workspace_bytes(int64_t N, int B, int d);
+int mfcd_shard_pack(const float *U_shard, const float *V_shard, const mfcd_sample *batch, int Bk, int B, int d,
+                    int u_lo, int u_hi, int v_lo, int v_hi, float *xbuf, void *stream);
+int mfcd_shard_apply(float *U_shard, float *V_shard, float *mU, float *vU, float *mV, float *vV,
+                     const mfcd_sample *batch, int Bk, int B, const float *xbuf, int64_t step, int d, int u_lo,
+                     int u_hi, int v_lo, int v_hi, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, float *loss_terms, void *stream);
+int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                           const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0, int n,
+                           int m, int d, double lr, double beta1, double beta2, double eps, double weight_decay,
+                           float *loss_per_step, void *workspace, size_t workspace_bytes, void *comm, void *stream);
+
+/*
  * Dense UV^T pass against X [n][m] fp32 without materialising UV^T (MFMA fp32 tiles, fused
  * epilogue).  Replaces the GEMM + reductions of compute_reconstruction_error
  * (structure.py:940-952) and of compute_alpha_and_norm_ratios (structure.py:982-996, 1003-1009,
@@ -282,6 +315,33 @@ int mfcd_uvt_stats(const float *U, const float *V, const float *X, int n, int m,
  */
 int mfcd_uvt_rows(const float *U, const float *V, const int32_t *row_ids, int k, int n, int m,
                   int d, float *out, void *stream);
+
+/*
+ * BTL label generation on the device (replaces BTLPreferenceDataset._generate_labels,
+ * structure.py:493-519, and the host-side packing of the records): for each of T triplets (int32 u, i, j)
+ * score = sigmoid(scale * (X[u][i] - X[u][j])) in fp32, K Bernoulli(score) draws, and
+ *   soft == 0: K consecutive mfcd_sample records per triplet with labels 0/1 (out holds T*K records)
+ *   soft != 0: one record per triplet with z = mean of the K draws       (out holds T records)
+ * X is dense [n][m] fp32, or NULL with the factors A [n][dx], B [m][dx] of X = A B^T given instead (C4/C5 sizes).
+ * Randomness: Philox4x32-10 keyed by `seed`, counter = (triplet index, draw group): reproducible for a seed,
+ * independent of launch geometry; NOT the reference's CPU generator stream (distributional parity only).
+ * Indices are not validated here (mfcd_check_samples on the output does that).
+ */
+int mfcd_generate_labels(const int32_t *triplets, int64_t T, const float *X, int n, int m, const float *A,
+                         const float *B, int dx, double scale, int K, int soft, uint64_t seed,
+                         mfcd_sample *out, void *stream);
+
+/*
+ * Per-row Spearman rank correlation: rho[r] = Pearson correlation of the average ranks
+ * (scipy.stats.rankdata semantics: ties share the mean of their positions; -0.0 ties with +0.0) of row r of A
+ * [rows][lda] and row r of X [rows][ldx], m <= mfcd_spearman_max_columns() (16384) columns each.  Replaces the
+ * reference's Python loop of scipy.stats.spearmanr over the rows of the centred U V^T and X (structure.py:1023-1031);
+ * the caller forms the rows of U V^T with a plain library GEMM.  One workgroup per row: bitonic sort in LDS, exact
+ * integer sums of the doubled centred ranks, rho in f64 (NaN for a constant row, as scipy).  Deterministic.
+ */
+int mfcd_spearman_max_columns(void);
+int mfcd_spearman_rows(const float *A, int64_t lda, const float *X, int64_t ldx, int rows, int m,
+                       double *rho, void *stream);
 
 #ifdef __cplusplus
 }

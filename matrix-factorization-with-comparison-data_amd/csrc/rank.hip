@@ -1,0 +1,128 @@
+// rank.hip — per-row Spearman rank correlation on gfx950.
+//
+// Replaces the reference's Python loop of scipy.stats.spearmanr over the rows of the centred U V^T and X
+// (structure.py:1023-1031): rho[r] = Pearson correlation of the AVERAGE ranks (scipy.stats.rankdata, ties share the
+// mean of their positions) of row r of A and row r of X.
+//
+// One workgroup of 1024 threads per row pair, everything in LDS:
+//   * the row becomes (sortable 32-bit key, 16-bit column) pairs, padded to a power of two P <= 16384 with keys that
+//     sort last; -0.0 ranks as +0.0 (numeric equality, as numpy compares);
+//   * bitonic sort of the pairs (P/2 compare-exchanges per stage, log2(P)(log2(P)+1)/2 stages, one barrier each);
+//   * every run of equal keys gets the doubled average rank 2*rank = first + last + 2 (0-based positions), written by
+//     the thread that holds the run's first element;
+//   * A's doubled ranks are scattered back to column order (u16); during X's pass each sorted element looks up its
+//     column's A rank, and the three sums of the correlation are accumulated as EXACT 64-bit integers of the doubled,
+//     centred ranks (|2 rank - (m+1)| <= m, sums <= 4 m^3 < 2^46), reduced in fixed order; rho is formed in f64.
+// The result is therefore independent of thread scheduling and equals scipy's float64 computation to rounding.
+// LDS: 6 P + 2 m bytes (128 KiB at m = 16384).  Rows longer than 16384 are not handled here (host: torch ops).
+#include "common.h"
+
+namespace {
+
+constexpr int kRankThreads = 1024;
+constexpr int kRankMaxCols = 16384;
+
+__device__ __forceinline__ unsigned sortable_key(float f)
+{
+    if (f == 0.0f) f = 0.0f;                       // -0.0 -> +0.0
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__device__ __forceinline__ long long block_sum_i64(long long v, long long *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, MFCD_WAVE);
+    __syncthreads();                               // red[] may still be read from the previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long t = 0;
+    for (int w = 0; w < kRankThreads / 64; ++w) t += red[w];   // fixed order, every thread
+    return t;
+}
+
+__global__ __launch_bounds__(kRankThreads) void spearman_rows_kernel(const float *__restrict__ A, int64_t lda,
+                                                                     const float *__restrict__ X, int64_t ldx, int m,
+                                                                     int P, double *__restrict__ rho)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *key = reinterpret_cast<unsigned *>(smem);                       // [P]
+    unsigned short *idx = reinterpret_cast<unsigned short *>(key + P);         // [P]
+    unsigned short *ra2 = idx + P;                                             // [m] doubled rank of A by column
+    __shared__ long long red[kRankThreads / 64];
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const long long centre = (long long)m + 1;     // 2 * mean rank
+    long long saa = 0, sxx = 0, sxy = 0;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const float *row = pass == 0 ? A + r * lda : X + r * ldx;
+        for (int p = tid; p < P; p += kRankThreads) {
+            key[p] = p < m ? sortable_key(row[p]) : 0xFFFFFFFFu;
+            idx[p] = (unsigned short)p;
+        }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (P >> 1); t += kRankThreads) {
+                    const int i = 2 * j * (t / j) + (t % j), l = i + j;
+                    const unsigned a = key[i], b = key[l];
+                    if ((a > b) == ((i & k) == 0)) {
+                        key[i] = b;
+                        key[l] = a;
+                        const unsigned short ia = idx[i];
+                        idx[i] = idx[l];
+                        idx[l] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // NaN keys (sortable value above +inf's) and the padding sort last; a padded key can only tie with a real
+        // 0xFFFFFFFF key, which no finite float or infinity produces
+        long long s_own = 0, s_xy = 0;
+        for (int p = tid; p < m; p += kRankThreads) {
+            const unsigned kp = key[p];
+            if (p > 0 && key[p - 1] == kp) continue;            // not the first element of its run
+            int e = p;
+            while (e + 1 < m && key[e + 1] == kp) ++e;
+            const long long c2 = (long long)(p + e + 2) - centre;   // doubled, centred average rank of the run
+            s_own += c2 * c2 * (long long)(e - p + 1);
+            if (pass == 0) {
+                for (int q = p; q <= e; ++q) ra2[idx[q]] = (unsigned short)(p + e + 2);
+            } else {
+                for (int q = p; q <= e; ++q) s_xy += c2 * ((long long)ra2[idx[q]] - centre);
+            }
+        }
+        if (pass == 0) saa = s_own;
+        else { sxx = s_own; sxy = s_xy; }
+        __syncthreads();                                         // ra2 complete / key, idx free for the next pass
+    }
+    const long long Saa = block_sum_i64(saa, red), Sxx = block_sum_i64(sxx, red), Sxy = block_sum_i64(sxy, red);
+    if (tid == 0) rho[r] = (double)Sxy / (sqrt((double)Saa) * sqrt((double)Sxx));   // 0/0 -> NaN, as scipy for constants
+}
+
+}  // namespace
+
+extern "C" int mfcd_spearman_max_columns(void) { return kRankMaxCols; }
+
+extern "C" int mfcd_spearman_rows(const float *A, int64_t lda, const float *X, int64_t ldx, int rows, int m,
+                                  double *rho, void *stream)
+{
+    if (!A || !X || !rho || rows < 0 || m <= 0 || lda < m || ldx < m) return MFCD_EINVAL;
+    if (m > kRankMaxCols) return MFCD_EINVAL;
+    if (rows == 0) return 0;
+    int P = 2;
+    while (P < m) P <<= 1;
+    const size_t lds = (size_t)P * 6 + (size_t)m * 2;
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)spearman_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+        allowed = lds;
+    }
+    hipLaunchKernelGGL(spearman_rows_kernel, dim3((unsigned)rows), dim3(kRankThreads), lds, (hipStream_t)stream, A, lda, X,
+                       ldx, m, P, rho);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}

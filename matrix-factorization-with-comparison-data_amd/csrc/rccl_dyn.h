@@ -13,6 +13,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -32,6 +33,7 @@ inline const RcclApi &rccl()
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
         a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
+        a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather;
         return a;

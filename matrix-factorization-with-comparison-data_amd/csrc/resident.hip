@@ -23,6 +23,7 @@
 //   * summation order per row is batch order, as in the streaming kernel; results are deterministic.
 //
 // The arithmetic is the same as train.hip's (common.h helpers): structure.py:847-851 per step.
+#include <cstring>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -143,20 +144,36 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus)
 }
 
 // ---- prologue of a resident / local call: ONE kernel ----
-//  (a) copies the call's host-built table (ResidentCold + per-step Adam scalars) from the pinned staging slot,
-//      which the kernel reads directly over the host link, into the workspace (no separate H2D copy on the stream);
+//  (a) copies the call's host-built table (ResidentCold + per-step Adam scalars) into the workspace: out of the
+//      kernel-argument segment for calls of up to 223 steps, else from the pinned staging slot, which the kernel reads
+//      directly over the host link (no separate H2D copy on the stream either way);
 //  (b) resident form only: translates the call's samples to VIRTUAL row ids (xs) and builds the touch strings:
 //      touch[string][k >> 5] bit (k & 31) = batch k holds a sample with a row of that string (one string per wave,
 //      or per virtual row for waves of up to 4 rows: the kernel's ROWWIN).  The strings are all-zero on entry
 //      (workspace init + every wave clears its own strings at the end of a launch).
-__global__ __launch_bounds__(256) void train_prologue_kernel(const uint4 *__restrict__ stage_host,
+// INLINE: the table travels in the kernel-argument segment itself (first parameter, so it sits at offset 0 of the
+// segment, which every lane can address); short calls then need no read over the host link at all.
+constexpr int kInlineStageUnits = 232;   // 16-byte units: ResidentCold (8) + 224 step scalars; 3712 bytes of kernarg
+struct InlineStage {
+    uint4 v[kInlineStageUnits];
+};
+
+template <bool INLINE>
+__global__ __launch_bounds__(256) void train_prologue_kernel(InlineStage inl, const uint4 *__restrict__ stage_host,
                                                              uint4 *__restrict__ stage_dev, int stage_units,
                                                              const mfcd_sample *__restrict__ samples, int64_t N, int B,
                                                              int n, int m, int rows_per_wave, int KW, int want_touch,
                                                              mfcd_sample *__restrict__ xs, unsigned *__restrict__ touch)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t < stage_units) stage_dev[t] = stage_host[t];
+    if (t < stage_units) {
+        if constexpr (INLINE) {
+            const uint4 *ka = (const uint4 *)__builtin_amdgcn_kernarg_segment_ptr();
+            stage_dev[t] = ka[t];
+        } else {
+            stage_dev[t] = stage_host[t];
+        }
+    }
     if (!xs || t >= N) return;
     const RowMap rm = make_row_map(n, m);
     mfcd_sample s = samples[t];
@@ -182,15 +199,23 @@ size_t resident_touch_bytes(int64_t K)
     return sizeof(unsigned) * (size_t)(4 * kResidentMaxWaves + 4) * (size_t)resident_touch_words(K);   // <= 4 rows/wave
 }
 
-int launch_train_prologue(const void *stage_host_devview, void *stage_dev, size_t stage_bytes,
+int launch_train_prologue(const void *stage_host, const void *stage_host_devview, void *stage_dev, size_t stage_bytes,
                           const mfcd_sample *samples, int64_t N, int B, int n, int m, int rows_per_wave, int KW,
                           int want_touch, mfcd_sample *xs, unsigned *touch, hipStream_t st)
 {
     const int units = (int)((stage_bytes + 15) / 16);
     const int64_t items = xs ? (N > units ? N : units) : units;
-    hipLaunchKernelGGL(train_prologue_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                       (const uint4 *)stage_host_devview, (uint4 *)stage_dev, units, samples, N, B, n, m,
-                       rows_per_wave, KW, want_touch, xs, touch);
+    const dim3 grid((unsigned)((items + 255) / 256));
+    if (units <= kInlineStageUnits) {
+        InlineStage inl;
+        std::memcpy(inl.v, stage_host, (size_t)units * 16);
+        hipLaunchKernelGGL(train_prologue_kernel<true>, grid, dim3(256), 0, st, inl, (const uint4 *)nullptr,
+                           (uint4 *)stage_dev, units, samples, N, B, n, m, rows_per_wave, KW, want_touch, xs, touch);
+    } else {
+        static const InlineStage none{};
+        hipLaunchKernelGGL(train_prologue_kernel<false>, grid, dim3(256), 0, st, none, (const uint4 *)stage_host_devview,
+                           (uint4 *)stage_dev, units, samples, N, B, n, m, rows_per_wave, KW, want_touch, xs, touch);
+    }
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }

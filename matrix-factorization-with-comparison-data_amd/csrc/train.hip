@@ -93,14 +93,19 @@ __device__ __forceinline__ void store_vec(float *p, const float (&r)[VEC])
 // E = 256 * VEC * CHUNKS elements per workgroup.
 // MODE 0: the fused step.  MODE 1 (data-parallel, before the all-reduce): only this rank's dense gradient,
 // Gu/Gv[e] = sum of the local samples' row gradients (no Adam, parameters untouched).  MODE 2 (after the
-// all-reduce): Adam from the dense gradient Gu/Gv, no batch scan.
+// all-reduce): Adam from the dense gradient Gu/Gv, no batch scan.  MODE 3 (row-sharded state, mfcd_shard_*): the
+// tables are this rank's SHARDS (rows [u_off, u_off + n) of U, [v_off, v_off + m) of V), the batch names GLOBAL rows,
+// and the three rows of every sample come from the exchange buffer g_in = xbuf[role][g_stride][d] (the rows as they
+// were before this step, gathered from their owners), so the update is in place; workgroup 0 also forms every
+// sample's BCE term, which makes the step's loss available on every rank without a collective.
 template <int VEC, int CHUNKS, int MODE = 0, typename TP = float>
 __global__ __launch_bounds__(256) void train_step_kernel(
     const TP *__restrict__ Uin, const TP *__restrict__ Vin, TP *__restrict__ Uout,
     TP *__restrict__ Vout, float *__restrict__ mU, float *__restrict__ vU, float *__restrict__ mV,
     float *__restrict__ vV, const mfcd_sample *__restrict__ batch, const float *__restrict__ g_in,
     int Bk, float inv_batch, int n, int m, int d, int blocksU, AdamConst ac,
-    float *__restrict__ loss_terms, float *__restrict__ Gu, float *__restrict__ Gv, int g_stride)
+    float *__restrict__ loss_terms, float *__restrict__ Gu, float *__restrict__ Gv, int g_stride, int u_off = 0,
+    int v_off = 0)
 {
     constexpr int E = 256 * VEC * CHUNKS;
     extern __shared__ __attribute__((aligned(16))) float sg[];  // [(row_hi-row_lo)*d] sparse row gradients
@@ -140,7 +145,8 @@ __global__ __launch_bounds__(256) void train_step_kernel(
     for (int base = 0; MODE != 2 && base < Bk; base += MFCD_WAVE) {
         const int t = base + lane;
         if (t < Bk) {
-            const mfcd_sample s = batch[t];
+            mfcd_sample s = batch[t];
+            if constexpr (MODE == 3) { s.u -= u_off; s.i -= v_off; s.j -= v_off; }   // global -> shard-local rows
             if (isV)
                 any |= (s.i >= row_lo && s.i < row_hi) | (s.j >= row_lo && s.j < row_hi);
             else
@@ -148,6 +154,22 @@ __global__ __launch_bounds__(256) void train_step_kernel(
         }
     }
     if constexpr (MODE != 2) any = __syncthreads_or(any);
+
+    if constexpr (MODE == 3) {
+        // every rank holds all three rows of every sample: workgroup 0 records all BCE terms (same dot-product order as
+        // the owner-recorded term of MODE 0)
+        if (blockIdx.x == 0 && loss_terms) {
+            const float *xb = reinterpret_cast<const float *>(g_in);
+            for (int t = wave; t < Bk; t += 4) {
+                const float *ur = xb + (int64_t)t * d, *vi = xb + ((int64_t)g_stride + t) * d,
+                            *vj = xb + ((int64_t)2 * g_stride + t) * d;
+                float acc = 0.0f;
+                for (int k = lane; k < d; k += MFCD_WAVE) acc += ur[k] * (vi[k] - vj[k]);
+                const float p = sigmoid_f32(wave_sum64(acc));
+                if (lane == 0) loss_terms[t] = bce_term_f32(p, batch[t].z);
+            }
+        }
+    }
 
     if (MODE != 2 && any) {
         const int nsg = (row_hi - row_lo) * d;
@@ -159,7 +181,10 @@ __global__ __launch_bounds__(256) void train_step_kernel(
             mfcd_sample s;
             s.u = s.i = s.j = -1;
             s.z = 0.0f;
-            if (t < Bk) s = batch[t];
+            if (t < Bk) {
+                s = batch[t];
+                if constexpr (MODE == 3) { s.u -= u_off; s.i -= v_off; s.j -= v_off; }
+            }
             const bool hu = !isV && s.u >= row_lo && s.u < row_hi && ((s.u - row_lo) & 3) == wave;
             const bool hi = isV && s.i >= row_lo && s.i < row_hi && ((s.i - row_lo) & 3) == wave;
             const bool hj = isV && s.j >= row_lo && s.j < row_hi && ((s.j - row_lo) & 3) == wave;
@@ -172,8 +197,14 @@ __global__ __launch_bounds__(256) void train_step_kernel(
                           jj = __shfl(s.j, tl, MFCD_WAVE);
                 const float zz = __shfl(s.z, tl, MFCD_WAVE);
                 const TP *ur = Uin + (int64_t)uu * d, *vi = Vin + (int64_t)ii * d, *vj = Vin + (int64_t)jj * d;
+                if constexpr (MODE == 3) {   // rows of sample base + tl as gathered before this step (fp32 only)
+                    const TP *xb = reinterpret_cast<const TP *>(g_in);
+                    ur = xb + (int64_t)(base + tl) * d;
+                    vi = xb + ((int64_t)g_stride + base + tl) * d;
+                    vj = xb + ((int64_t)2 * g_stride + base + tl) * d;
+                }
                 float g;
-                if (g_in) {
+                if (MODE != 3 && g_in) {
                     g = g_in[(base + tl) * g_stride];   // stride 2: interleaved {g, term} pairs of the DP exchange
                 } else {
                     float acc = 0.0f;
@@ -181,7 +212,7 @@ __global__ __launch_bounds__(256) void train_step_kernel(
                     const float p = sigmoid_f32(wave_sum64(acc));
                     g = bce_sigmoid_backward_f32(p, zz, inv_batch);
                     // the workgroup that owns the first element of row u records the loss term
-                    if (((mu >> tl) & 1ull) && loss_terms && lane == 0) {
+                    if (MODE != 3 && ((mu >> tl) & 1ull) && loss_terms && lane == 0) {
                         const int64_t first = (int64_t)uu * d;
                         if (first >= e0 && first < e1) loss_terms[base + tl] = bce_term_f32(p, zz);
                     }
@@ -361,23 +392,23 @@ template <int VEC, int CHUNKS, int MODE, typename TP>
 void launch_step(const Plan &pl, hipStream_t st, const TP *Uin, const TP *Vin, TP *Uout, TP *Vout,
                  float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
                  float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu, float *Gv,
-                 int g_stride)
+                 int g_stride, int u_off, int v_off)
 {
     hipLaunchKernelGGL((train_step_kernel<VEC, CHUNKS, MODE, TP>), dim3(pl.blocksU + pl.blocksV), dim3(256), pl.lds, st,
                        Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, n, m, d, pl.blocksU, ac,
-                       loss_terms, Gu, Gv, g_stride);
+                       loss_terms, Gu, Gv, g_stride, u_off, v_off);
 }
 
 template <int MODE = 0, typename TP = float>
 void dispatch_step(const Plan &pl, hipStream_t st, const TP *Uin, const TP *Vin, TP *Uout, TP *Vout,
                    float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, const float *g_in, int Bk,
                    float inv_batch, int n, int m, int d, const AdamConst &ac, float *loss_terms, float *Gu = nullptr,
-                   float *Gv = nullptr, int g_stride = 1)
+                   float *Gv = nullptr, int g_stride = 1, int u_off = 0, int v_off = 0)
 {
 #define MFCD_CASE(V, C)                                                                                              \
     if (pl.vec == V && pl.chunks == C)                                                                               \
         return launch_step<V, C, MODE, TP>(pl, st, Uin, Vin, Uout, Vout, mU, vU, mV, vV, batch, g_in, Bk, inv_batch, \
-                                           n, m, d, ac, loss_terms, Gu, Gv, g_stride);
+                                           n, m, d, ac, loss_terms, Gu, Gv, g_stride, u_off, v_off);
     MFCD_CASE(4, 1) MFCD_CASE(4, 2) MFCD_CASE(4, 4) MFCD_CASE(4, 8)
     MFCD_CASE(1, 1) MFCD_CASE(1, 2) MFCD_CASE(1, 4) MFCD_CASE(1, 8)
 #undef MFCD_CASE
@@ -539,6 +570,8 @@ WsState *find_ws(void *workspace)
 
 // A staging slot nobody reads any more, at least `need` bytes.  Blocks only when kStageSlots calls of this workspace
 // are still queued on the device (bounded run-ahead of the host), never behind the previous call.
+int stage_reserve(StageSlot &s, size_t need);
+
 int stage_acquire(WsState &S, size_t need, StageSlot **out)
 {
     StageSlot &s = S.slot[S.next++ % kStageSlots];
@@ -546,6 +579,15 @@ int stage_acquire(WsState &S, size_t need, StageSlot **out)
         MFCD_HIP_TRY(hipEventSynchronize(s.ev));
         s.pending = false;
     }
+    if (int rc = stage_reserve(s, need)) return rc;
+    *out = &s;
+    return 0;
+}
+
+// pinned memory and event of one slot (both are created when the workspace is initialised: a pinned allocation costs
+// ~0.1-0.2 ms of host time, which must not land on a training call)
+int stage_reserve(StageSlot &s, size_t need)
+{
     if (!s.ev) MFCD_HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
     if (s.cap < need) {
         if (s.host) (void)hipHostFree(s.host);
@@ -558,7 +600,6 @@ int stage_acquire(WsState &S, size_t need, StageSlot **out)
         }
         MFCD_HIP_TRY(hipHostGetDevicePointer(&s.devview, s.host, 0));
     }
-    *out = &s;
     return 0;
 }
 
@@ -602,6 +643,7 @@ extern "C" int mfcd_set_tuning(int key, int64_t value)
             if (value < 0 || value > 0x7fffffff) return MFCD_EINVAL;
             t.spin_limit = value == 0 ? mfcd_detail::kSpinLimitDefault : (unsigned)value;
             return 0;
+        case MFCD_TUNE_UVT_WPE128: return mfcd_detail::set_uvt_wpe128((int)value);
         case MFCD_TUNE_SHORT_CALL_STEPS:
             if (value < 0 || value > 0x7fffffff) return MFCD_EINVAL;
             t.short_call_steps = (int)value;
@@ -631,6 +673,8 @@ extern "C" int mfcd_train_workspace_init(void *workspace, size_t workspace_bytes
     S->N_cap = N_cap > 0 ? N_cap : 1;
     S->B = B; S->n = n; S->m = m; S->d = d;
     S->L = L;
+    for (auto &sl : S->slot)
+        if (int rc = stage_reserve(sl, L.stage_bytes)) return rc;
     std::lock_guard<std::mutex> lock(g_ws_mu);
     g_ws[workspace] = std::move(S);
     return 0;
@@ -744,12 +788,10 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
         }
         const int rpw = resident ? 64 * fc.rp.Q / d : 0;
         const int want_touch = resident && fc.rp.lookahead > 0;
-        if (int rc = mfcd_detail::launch_train_prologue(slot->devview, base + L.stage_off, need, samples, N, B, n, m, rpw,
+        if (int rc = mfcd_detail::launch_train_prologue(slot->host, slot->devview, base + L.stage_off, need, samples, N, B, n, m, rpw,
                                                         mfcd_detail::resident_touch_words(nsteps), want_touch, xs, touch,
                                                         st))
             return rc;
-        MFCD_HIP_TRY(hipEventRecord(slot->ev, st));
-        slot->pending = true;
 
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing_us) {
@@ -772,6 +814,10 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
                                loss_per_step);
             MFCD_HIP_TRY(hipGetLastError());
         }
+        // the slot is free again once the prologue has read it; recorded behind the call's last launch so that the
+        // record does not sit between two launches (any later point of the stream implies the prologue is done)
+        MFCD_HIP_TRY(hipEventRecord(slot->ev, st));
+        slot->pending = true;
         if (timing_us) {
             MFCD_HIP_TRY(hipEventSynchronize(e1));
             float ms = 0.0f;
@@ -1065,6 +1111,152 @@ extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, flo
     }
     if (loss_per_step) {
         hipLaunchKernelGGL(dp_loss_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, xbuf, N, (int)Bg, loss_per_step);
+        MFCD_HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-sharded training (strong scaling): rank r holds rows [lo_r, hi_r) of U, V and of their Adam
+// moments; the batch stays the reference's B (structure.py:668) and every rank sees the same records, so the run equals
+// the single-GPU run with the same B.  Per optimiser step: (1) every rank writes the rows of the batch it owns into an
+// exchange buffer xbuf[role][B][d] (zeros elsewhere), (2) ONE all-reduce(sum) of the buffer taken as 32-bit integers —
+// exactly one rank contributes non-zero bits per row, so the sum reproduces the rows bit for bit — (3) the fused step
+// (MODE 3 of train_step_kernel) over the shard, in place, with the dense Adam sweep over 1/R of the state.
+namespace {
+
+__global__ __launch_bounds__(256) void shard_pack_kernel(const float *__restrict__ Us, const float *__restrict__ Vs,
+                                                         const mfcd_sample *__restrict__ batch, int Bk, int Bcap, int d,
+                                                         int u_off, int nu, int v_off, int nv, float *__restrict__ xbuf,
+                                                         int merge)
+{
+    // merge = 0: every row of the buffer is written (zeros where this rank owns nothing): the input of the all-reduce;
+    // merge = 1: only owned rows are written on top of what is there (single-process rehearsal of the all-reduce)
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // (role, t)
+    if (w >= 3 * Bcap) return;
+    const int role = w / Bcap, t = w - role * Bcap;
+    const float *src = nullptr;
+    if (t < Bk) {
+        const mfcd_sample s = batch[t];
+        const int row = role == 0 ? s.u - u_off : (role == 1 ? s.i : s.j) - v_off;
+        if (row >= 0 && row < (role == 0 ? nu : nv)) src = (role == 0 ? Us : Vs) + (int64_t)row * d;
+    }
+    if (merge && !src) return;
+    float *dst = xbuf + (int64_t)w * d;
+    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] = src ? src[k] : 0.0f;
+}
+
+void shard_range(int rows, int rank, int world, int *lo, int *hi)
+{
+    *lo = (int)((int64_t)rows * rank / world);
+    *hi = (int)((int64_t)rows * (rank + 1) / world);
+}
+
+size_t shard_xbuf_bytes(int B, int d) { return align256(sizeof(float) * 3 * (size_t)B * d); }
+
+}  // namespace
+
+extern "C" int mfcd_shard_rows(int rows, int rank, int world, int *lo, int *hi)
+{
+    if (rows <= 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return MFCD_EINVAL;
+    shard_range(rows, rank, world, lo, hi);
+    return 0;
+}
+
+extern "C" size_t mfcd_shard_workspace_bytes(int64_t N, int B, int d)
+{
+    if (N < 0 || B <= 0 || d <= 0) return 0;
+    return shard_xbuf_bytes(B, d) + align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
+}
+
+extern "C" int mfcd_shard_pack(const float *U_shard, const float *V_shard, const mfcd_sample *batch, int Bk, int B,
+                               int d, int u_lo, int u_hi, int v_lo, int v_hi, float *xbuf, void *stream)
+{
+    if (!batch || !xbuf || Bk < 0 || B <= 0 || Bk > B || d <= 0 || d > MFCD_MAX_D || u_hi < u_lo || v_hi < v_lo)
+        return MFCD_EINVAL;
+    if ((u_hi > u_lo && !U_shard) || (v_hi > v_lo && !V_shard)) return MFCD_EINVAL;
+    hipLaunchKernelGGL(shard_pack_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, U_shard, V_shard,
+                       batch, Bk, B, d, u_lo, u_hi - u_lo, v_lo, v_hi - v_lo, xbuf, 0);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mfcd_shard_apply(float *U_shard, float *V_shard, float *mU, float *vU, float *mV, float *vV,
+                                const mfcd_sample *batch, int Bk, int B, const float *xbuf, int64_t step, int d,
+                                int u_lo, int u_hi, int v_lo, int v_hi, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, float *loss_terms, void *stream)
+{
+    if (!batch || !xbuf || Bk <= 0 || B <= 0 || Bk > B || d <= 0 || d > MFCD_MAX_D || step < 1) return MFCD_EINVAL;
+    const int nu = u_hi - u_lo, nv = v_hi - v_lo;
+    if (nu < 0 || nv < 0 || nu + nv <= 0) return MFCD_EINVAL;
+    if ((nu > 0 && (!U_shard || !mU || !vU)) || (nv > 0 && (!V_shard || !mV || !vV))) return MFCD_EINVAL;
+    const void *ptrs[] = {U_shard, V_shard, mU, vU, mV, vV, xbuf};
+    // an empty table side is legal (a rank may own rows of one table only when world > rows): one dummy row count
+    const Plan pl = make_plan(ptrs, 7, nu > 0 ? nu : 0, nv > 0 ? nv : 0, d);
+    const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step);
+    dispatch_step<3, float>(pl, (hipStream_t)stream, U_shard, V_shard, U_shard, V_shard, mU, vU, mV, vV, batch, xbuf, Bk,
+                            1.0f / (float)Bk, nu, nv, d, ac, loss_terms, nullptr, nullptr, B, u_lo, v_lo);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                                      const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0,
+                                      int n, int m, int d, double lr, double beta1, double beta2, double eps,
+                                      double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
+                                      void *comm, void *stream)
+{
+    if (n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D || N < 0 || B <= 0 || world < 1 || rank < 0 || rank >= world ||
+        step0 < 0)
+        return MFCD_EINVAL;
+    if (N == 0) return 0;
+    if (!samples || !workspace || !U || !V || !mU || !vU || !mV || !vV) return MFCD_EINVAL;
+    if (workspace_bytes < mfcd_shard_workspace_bytes(N, B, d)) return MFCD_EWORKSPACE;
+    const mfcd_detail::RcclApi *R = nullptr;
+    if (comm) {
+        R = &mfcd_detail::rccl();
+        if (!R->ok || !R->AllReduce) return MFCD_ERCCL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float *xbuf = (float *)workspace;
+    float *terms = (float *)((char *)workspace + shard_xbuf_bytes(B, d));
+    const int64_t nsteps = (N + B - 1) / B;
+    // with a communicator the table pointers are this rank's SHARDS; without one they are the FULL tables and this
+    // process plays every rank in turn (single-process rehearsal of any world size; exact, the protocol is the same)
+    const int r0 = comm ? rank : 0, r1 = comm ? rank + 1 : world;
+    for (int64_t k = 0; k < nsteps; ++k) {
+        const int64_t off = k * B;
+        const int Bk = (int)((N - off) < B ? (N - off) : B);
+        for (int r = r0; r < r1; ++r) {
+            int ul, uh, vl, vh;
+            shard_range(n, r, world, &ul, &uh);
+            shard_range(m, r, world, &vl, &vh);
+            const int64_t uo = comm ? 0 : (int64_t)ul * d, vo = comm ? 0 : (int64_t)vl * d;
+            if (comm || r == r0) {
+                if (int rc = mfcd_shard_pack(U + uo, V + vo, samples + off, Bk, B, d, ul, uh, vl, vh, xbuf, stream))
+                    return rc;
+            } else {   // rehearsal: the other ranks' rows land on top of the first rank's zeros (disjoint ownership)
+                hipLaunchKernelGGL(shard_pack_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, st, U + uo, V + vo,
+                                   samples + off, Bk, B, d, ul, uh - ul, vl, vh - vl, xbuf, 1);
+            }
+        }
+        if (comm && R->AllReduce(xbuf, xbuf, (size_t)3 * B * d, ncclUint32, ncclSum, (ncclComm_t)comm, st) != ncclSuccess)
+            return MFCD_ERCCL;
+        for (int r = r0; r < r1; ++r) {
+            int ul, uh, vl, vh;
+            shard_range(n, r, world, &ul, &uh);
+            shard_range(m, r, world, &vl, &vh);
+            const int64_t uo = comm ? 0 : (int64_t)ul * d, vo = comm ? 0 : (int64_t)vl * d;
+            if (int rc = mfcd_shard_apply(U + uo, V + vo, mU + uo, vU + uo, mV + vo, vV + vo, samples + off, Bk, B, xbuf,
+                                          step0 + k + 1, d, ul, uh, vl, vh, lr, beta1, beta2, eps, weight_decay,
+                                          r == r0 ? terms + off : nullptr, stream))
+                return rc;
+        }
+    }
+    if (loss_per_step) {
+        hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms,
+                           (const mfcd_sample *)nullptr, N, B, loss_per_step);
         MFCD_HIP_TRY(hipGetLastError());
     }
     return 0;

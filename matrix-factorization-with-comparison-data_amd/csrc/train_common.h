@@ -161,12 +161,14 @@ extern Tuning g_tune;
 
 extern int g_resident_math;
 
+int set_uvt_wpe128(int v);   // uvt.hip
+
 ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus);
 int resident_lookahead(int64_t N, int B, int n, int m);
 
 // One kernel in front of a resident / local launch: pinned staging slot -> workspace, and (xs != nullptr) the
 // translated samples + touch strings of the resident form.
-int launch_train_prologue(const void *stage_host_devview, void *stage_dev, size_t stage_bytes,
+int launch_train_prologue(const void *stage_host, const void *stage_host_devview, void *stage_dev, size_t stage_bytes,
                           const mfcd_sample *samples, int64_t N, int B, int n, int m, int rows_per_wave, int KW,
                           int want_touch, mfcd_sample *xs, unsigned *touch, hipStream_t st);
 

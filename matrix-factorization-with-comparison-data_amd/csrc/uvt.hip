@@ -6,7 +6,8 @@
 // Algebra that removes passes over the n x m product (G = U V^T):
 //   column-centred  G - colmean(G) = G[r][c] - cm[c],  cm[c] = mean_r(U) . V[c]     (structure.py:943)
 //   row-centred     G - rowmean(G) = G[r][c] - rm[r],  rm[r] = U[r] . mean_c(V)     (structure.py:985)
-//   row-centred X   c = X[r][c] - xm[r]; xm and sum c^2, sum x^2 come from one f64 pre-pass over X
+//   row-centred X   c = X[r][c] - xm[r]; xm, sum c^2 and sum x^2 are per-row sums of the SAME sweep (tiled form: taken
+//                   relative to a per-split shift and re-centred in f64 afterwards; generic form: an f64 pre-pass)
 // so one MFMA pass with a fused epilogue yields, per row, sum a*c and sum a*a (a = G - rm) and,
 // globally, sum (G - cm - sX)^2.  Every scalar the reference derives (alpha, norm ratio, scaled
 // errors, per-row Pearson / slope / alpha_i) is a function of those sums (host side, f64).
@@ -38,6 +39,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSlices = 256;  // row slices for the deterministic column-sum of U and V
+constexpr int kTiledRowSums = 6;   // doubles the tiled kernel leaves per (split, row) for the final kernel
 
 // a table of `rows` rows is cut into slices of >= 128 rows (at most kSlices of them)
 __host__ __device__ inline int slices_for(int rows) { return rows >= 128 * kSlices ? kSlices : (rows + 127) / 128; }
@@ -83,37 +85,72 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     }
 }
 
-// bar[table][k] = (sum over slices) / rows, stored fp32 (the reference works on fp32 tensors)
+// bar[table][k] = (sum over slices) / rows, stored fp32 (large tables only; small ones do this inside
+// centre_vectors_kernel).  Same summation order as there.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restrict__ part, int n, int m, int d,
                                                            float *__restrict__ bar)
 {
     const int tab = blockIdx.y;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < d; k += gridDim.x * 256) {
-        double acc = 0.0;
-        const int nsl = slices_for(tab ? m : n);
-        for (int s = 0; s < nsl; ++s) acc += part[((size_t)tab * kSlices + s) * d + k];
-        bar[(size_t)tab * d + k] = (float)(acc / (double)(tab ? m : n));
+        const int rows = tab ? m : n, nsl = slices_for(rows);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int sl = 0;
+        for (; sl + 3 < nsl; sl += 4) {
+            a0 += part[((size_t)tab * kSlices + sl) * d + k];
+            a1 += part[((size_t)tab * kSlices + sl + 1) * d + k];
+            a2 += part[((size_t)tab * kSlices + sl + 2) * d + k];
+            a3 += part[((size_t)tab * kSlices + sl + 3) * d + k];
+        }
+        for (; sl < nsl; ++sl) a0 += part[((size_t)tab * kSlices + sl) * d + k];
+        bar[(size_t)tab * d + k] = (float)(((a0 + a1) + (a2 + a3)) / (double)rows);
     }
 }
 
-// One wave per row: rm[r] = U[r].vbar (rows 0..n-1), cm[c] = ubar.V[c] (rows n..n+m-1); f64 accumulate.
+// rm[r] = U[r].vbar (rows 0..n-1), cm[c] = ubar.V[c] (rows n..n+m-1); f64 accumulate, stored fp32 (the reference
+// works on fp32 tensors).  A workgroup first forms ubar, vbar = (sum over slices) / rows from the partial column sums
+// (fixed order; every workgroup repeats this small reduction instead of a launch of its own), then takes
+// `rows_per_block` consecutive rows of [U; V], one wave per row.
 __global__ __launch_bounds__(256) void centre_vectors_kernel(const float *__restrict__ U, const float *__restrict__ V,
-                                                             const float *__restrict__ bar, int n, int m, int d,
-                                                             float *__restrict__ rm, float *__restrict__ cm)
+                                                             const double *__restrict__ part,
+                                                             const float *__restrict__ bar_pre, int n, int m, int d,
+                                                             int rows_per_block, float *__restrict__ rm,
+                                                             float *__restrict__ cm)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= (int64_t)n + m) return;
-    const bool isV = w >= n;
-    const float *row = isV ? V + (w - n) * d : U + w * d;
-    const float *other = isV ? bar : bar + d;  // V rows pair with ubar (bar[0]), U rows with vbar (bar[1])
-    double acc = 0.0;
-    for (int k = lane; k < d; k += MFCD_WAVE) acc += (double)row[k] * (double)other[k];
+    extern __shared__ __attribute__((aligned(16))) float bar[];   // [2][d]: ubar, vbar
+    for (int idx = threadIdx.x; idx < 2 * d; idx += 256) {
+        if (bar_pre) {   // large tables: colsum_final_kernel has reduced the partial sums once
+            bar[idx] = bar_pre[idx];
+            continue;
+        }
+        const int tab = idx / d, k = idx - tab * d;
+        const int rows = tab ? m : n, nsl = slices_for(rows);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // same order in every workgroup: (s0+s4+..)+(s1+..)+..
+        int sl = 0;
+        for (; sl + 3 < nsl; sl += 4) {
+            a0 += part[((size_t)tab * kSlices + sl) * d + k];
+            a1 += part[((size_t)tab * kSlices + sl + 1) * d + k];
+            a2 += part[((size_t)tab * kSlices + sl + 2) * d + k];
+            a3 += part[((size_t)tab * kSlices + sl + 3) * d + k];
+        }
+        for (; sl < nsl; ++sl) a0 += part[((size_t)tab * kSlices + sl) * d + k];
+        bar[idx] = (float)(((a0 + a1) + (a2 + a3)) / (double)rows);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t w1 = w0 + rows_per_block < (int64_t)n + m ? w0 + rows_per_block : (int64_t)n + m;
+    for (int64_t w = w0 + wave; w < w1; w += 4) {
+        const bool isV = w >= n;
+        const float *row = isV ? V + (w - n) * d : U + w * d;
+        const float *other = isV ? bar : bar + d;  // V rows pair with ubar (bar[0]), U rows with vbar (bar[1])
+        double acc = 0.0;
+        for (int k = lane; k < d; k += MFCD_WAVE) acc += (double)row[k] * (double)other[k];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, MFCD_WAVE);
-    if (lane == 0) {
-        if (isV) cm[w - n] = (float)acc;
-        else rm[w] = (float)acc;
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, MFCD_WAVE);
+        if (lane == 0) {
+            if (isV) cm[w - n] = (float)acc;
+            else rm[w] = (float)acc;
+        }
     }
 }
 
@@ -358,10 +395,13 @@ __device__ __forceinline__ void lds_wait4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 
-template <int D, int NW, int TC, bool XV>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(D >= 256 ? 2 : 3)))
+// PFX: fetch a tile's X values one tile ahead (needs ~45 more registers: two register sets, two copies of the tile
+// body).  On for d <= 128, where an HBM round trip outlasts a tile's MFMA chain; off for d = 256, whose 128-MFMA chain
+// covers it and whose 128-register operand leaves no room.
+template <int D, int NW, int TC, bool XV, int WPE = 2, bool PFX = (D <= 128)>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE)))
 void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ X,
-                      const float *__restrict__ rm, const float *__restrict__ cm, const float *__restrict__ xm, int n,
+                      const float *__restrict__ rm, const float *__restrict__ cm, int n,
                       int m, float s, int cols_per_split, int splits, int row_blocks, double *__restrict__ part_rows,
                       double *__restrict__ part_err)
 {
@@ -418,18 +458,21 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
             u[4 * q + 0] = t.x; u[4 * q + 1] = t.y; u[4 * q + 2] = t.z; u[4 * q + 3] = t.w;
         }
     }
-    float rmv = rm[myrow], xmv = xm[myrow];
+    // The row statistics of X (mean, sum x^2, centred sum of squares) come out of THIS sweep (round 1 read X a second
+    // time for them): every term is taken relative to x0 = the row's first value in this split, so that the fp32
+    // per-tile sums do not cancel, and the final kernel re-centres in f64 (uvt_final_tiled_kernel).
+    float rmv = rm[myrow], x0v = X[(int64_t)myrow * m + c_begin];
     // every load so far is consumed HERE, before the loop: left pending, the wait for it would sit in front of the
     // first MFMA of every iteration (and, with an LDS-DMA in flight, be a full vmcnt(0))
 #pragma unroll
     for (int k = 0; k < D / 2; ++k) asm volatile("" : "+v"(u[k]));
-    asm volatile("" : "+v"(rmv), "+v"(xmv));
+    asm volatile("" : "+v"(rmv), "+v"(x0v));
     const float *xlane = X + (int64_t)myrow * m + 4 * half;   // + cb + 8g: this lane's 16-byte pieces of a tile
     // fragment address of tile j of a stage: row 32j + l31, chunks half*CPR/2 + q (one piece, consecutive)
     const int f0 = l31 * CPR + half * (CPR / 2);
     const unsigned frag0 = (unsigned)(((f0 >> 6) * PF + (f0 & 63) * 4) * 4);          // bytes, tile 0
     constexpr unsigned frag_step = (unsigned)((32 * CPR / 64) * PF * 4);              // bytes per tile (32 rows)
-    double sac = 0.0, saa = 0.0, err2 = 0.0;
+    double sac = 0.0, saa = 0.0, err2 = 0.0, ssa = 0.0, ssc = 0.0, sscc = 0.0;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -438,38 +481,45 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     unsigned long long cyc_chain = 0, cyc_epi = 0, cyc_sync = 0, cyc_dma = 0, n_tiles = 0;
 #endif
     int buf = 0;
-    for (int c0 = c_begin; c0 < c_end; c0 += TC) {
-        const float *cms = cmss[buf];
-        MFCD_STAMP(td0);
-        if (c0 + TC < c_end) issue_stage(c0 + TC, vts[buf ^ 1], cmss[buf ^ 1]);
-        MFCD_STAMP(td1);
-#if MFCD_UVT_STAMPS
-        cyc_dma += td1 - td0;
+    // X values of this lane's row for the tile at column cb: columns cb + 8g + 4*half + {0,1,2,3}, g = 0..3.
+    // They are fetched ONE TILE AHEAD (round 1 issued them at the top of their own tile): an HBM round trip is ~2 us,
+    // i.e. longer than the 64-MFMA chain of a d = 128 tile, so the epilogue used to stall on them (C3 58 % vs C5 81 %
+    // in-kernel).  The two register sets swap roles every tile (no copy: copying a pending load would wait for it).
+    auto load_x = [&](int cb, f32x4 (&xq)[4]) {
+        if (XV && cb + 32 <= c_end) {
+            const f32x4 *xp = reinterpret_cast<const f32x4 *>(xlane + cb);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#if MFCD_UVT_EXP == 1
+                xq[g] = f32x4{(float)cb, 1.f, 2.f, 3.f};
+#else
+                xq[g] = xp[2 * g];
 #endif
-        if (active) {
-#pragma unroll 1
-            for (int j = 0; j < TC / 32; ++j) {
-                const int cb = c0 + 32 * j;
-                if (cb >= c_end) continue;
+            }
+        } else {
+            const float *xrow = xlane - 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xq[r >> 2][r & 3] = xrow[min(cb + tile_row(r, half), m - 1)];
+        }
+    };
+    f32x4 xa[4], xb[4];
+    int tile_no = 0, pend = 0;
+    if (PFX && active) load_x(c_begin, xa);
+
+    auto tile = [&](int cb, int ncb, int j, const float *cms, f32x4 (&xq)[4], f32x4 (&xn)[4]) __attribute__((always_inline)) {
                 const bool full = cb + 32 <= c_end;   // wave-uniform
                 MFCD_STAMP(tt0);
-                // X values of this lane's row: columns cb + 8g + 4*half + {0,1,2,3}, g = 0..3
-                f32x4 xq[4];
-                if (XV && full) {
-                    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xlane + cb);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-#if MFCD_UVT_EXP == 1
-                        xq[g] = f32x4{(float)cb, 1.f, 2.f, 3.f};
-#else
-                        xq[g] = xp[2 * g];
-#endif
+                asm volatile("" ::: "memory");   // the stage's LDS-DMA (issued above) stays OLDER than this prefetch
+                pend = 0;
+                if constexpr (PFX) {
+                    if (ncb >= 0) {
+                        load_x(ncb, xn);
+                        pend = (XV && ncb + 32 <= c_end) ? 4 : 16;   // vector-memory operations the prefetch put in flight
                     }
                 } else {
-                    const float *xrow = xlane - 4 * half;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) xq[r >> 2][r & 3] = xrow[min(cb + tile_row(r, half), m - 1)];
+                    load_x(cb, xq);          // this tile's own values, 16 loads in flight under its MFMA chain
                 }
+                asm volatile("" ::: "memory");
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -481,6 +531,8 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                 // may have in flight only make the wait stricter).
                 constexpr int QB = 4, NB = D / 8 / QB;
                 const unsigned abase = lds_addr(vts[buf]) + frag0 + (unsigned)j * frag_step;
+                const unsigned cmaddr = lds_addr(cms + 32 * j + 4 * half);
+                f32x4 cq[4];
                 f32x4 t[2][QB];
                 lds_read16_issue<0>(t[0][0], abase);
                 lds_read16_issue<16>(t[0][1], abase);
@@ -493,6 +545,13 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                         lds_wait4<QB>(t[bi & 1][0], t[bi & 1][1], t[bi & 1][2], t[bi & 1][3]);
                     } else {
                         lds_wait4<0>(t[bi & 1][0], t[bi & 1][1], t[bi & 1][2], t[bi & 1][3]);
+                        // the tile's 16 column means, under the last 16 MFMAs (inline asm like the fragment reads: a
+                        // compiler-visible ds_read would drain every outstanding vector-memory operation first, i.e.
+                        // the X values just requested for the NEXT tile)
+                        lds_read16_issue<0>(cq[0], cmaddr);
+                        lds_read16_issue<32>(cq[1], cmaddr);
+                        lds_read16_issue<64>(cq[2], cmaddr);
+                        lds_read16_issue<96>(cq[3], cmaddr);
                     }
 #pragma unroll
                     for (int q = 0; q < QB; ++q) {
@@ -514,22 +573,23 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                 // flight, for everything: vmcnt(0)) to the top of the chain
                 // (tied to the accumulator so that it stays behind the last MFMA)
                 asm volatile("" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]));
-                // acc[4g+e] = (U V^T)[myrow][cb + 8g + 4*half + e]
-                const float *cmrow = cms + 32 * j + 4 * half;
-                float pac, paa, pe;
+                lds_wait4<0>(cq[0], cq[1], cq[2], cq[3]);
+                // acc[4g+e] = (U V^T)[myrow][cb + 8g + 4*half + e]; cq[g][e] = the matching column mean
+                float pac, paa, pe, psa, psc, pscc;
                 if (full) {   // two terms per instruction (v_pk_*_f32)
-                    const f32x2 rm2 = {rmv, rmv}, xm2 = {xmv, xmv}, s2 = {s, s};
+                    const f32x2 rm2 = {rmv, rmv}, x02 = {x0v, x0v}, s2 = {s, s};
                     f32x2 pac2 = {0.0f, 0.0f}, paa2 = {0.0f, 0.0f}, pe2 = {0.0f, 0.0f};
+                    f32x2 psa2 = {0.0f, 0.0f}, psc2 = {0.0f, 0.0f}, pscc2 = {0.0f, 0.0f};
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cmrow + 8 * g);
+                        const f32x4 c4 = cq[g];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const f32x2 g2 = {acc[4 * g + 2 * h], acc[4 * g + 2 * h + 1]};
                             const f32x2 x2 = {xq[g][2 * h], xq[g][2 * h + 1]};
                             const f32x2 c2 = {c4[2 * h], c4[2 * h + 1]};
                             const f32x2 av = g2 - rm2;                         // structure.py:985
-                            const f32x2 cv = x2 - xm2;                         // structure.py:987
+                            const f32x2 cv = x2 - x02;                         // structure.py:987, up to the shift x0 - xm
                             const f32x2 ev = (g2 - c2) - s2 * x2;              // structure.py:943, 949
 #if MFCD_UVT_EXP == 2
                             pe2 += av + cv + ev;
@@ -538,29 +598,41 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                             pac2 = __builtin_elementwise_fma(av, cv, pac2);
                             paa2 = __builtin_elementwise_fma(av, av, paa2);
                             pe2 = __builtin_elementwise_fma(ev, ev, pe2);
+                            psa2 += av;
+                            psc2 += cv;
+                            pscc2 = __builtin_elementwise_fma(cv, cv, pscc2);
                         }
                     }
                     pac = pac2.x + pac2.y;
                     paa = paa2.x + paa2.y;
                     pe = pe2.x + pe2.y;
+                    psa = psa2.x + psa2.y;
+                    psc = psc2.x + psc2.y;
+                    pscc = pscc2.x + pscc2.y;
                 } else {      // ragged last tile of the split: per-term column masks
-                    pac = paa = pe = 0.0f;
+                    pac = paa = pe = psa = psc = pscc = 0.0f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const bool ok = cb + tile_row(r, half) < c_end;
                         const float gv = acc[r], xv = xq[r >> 2][r & 3];
-                        const float cmv = cmrow[8 * (r >> 2) + (r & 3)];
+                        const float cmv = cq[r >> 2][r & 3];
                         const float av = ok ? gv - rmv : 0.0f;
-                        const float cv = xv - xmv;
+                        const float cv = ok ? xv - x0v : 0.0f;
                         const float ev = ok ? (gv - cmv) - s * xv : 0.0f;
                         pac = fmaf(av, cv, pac);
                         paa = fmaf(av, av, paa);
                         pe = fmaf(ev, ev, pe);
+                        psa += av;
+                        psc += cv;
+                        pscc = fmaf(cv, cv, pscc);
                     }
                 }
                 sac += (double)pac;
                 saa += (double)paa;
                 err2 += (double)pe;
+                ssa += (double)psa;
+                ssc += (double)psc;
+                sscc += (double)pscc;
 #if MFCD_UVT_STAMPS
                 asm volatile("" : "+v"(sac), "+v"(saa), "+v"(err2));
                 MFCD_STAMP(tt2);
@@ -568,10 +640,38 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                 cyc_epi += tt2 - tt1;
                 n_tiles += 1;
 #endif
+    };
+
+    for (int c0 = c_begin; c0 < c_end; c0 += TC) {
+        const float *cms = cmss[buf];
+        MFCD_STAMP(td0);
+        if (c0 + TC < c_end) issue_stage(c0 + TC, vts[buf ^ 1], cmss[buf ^ 1]);
+        MFCD_STAMP(td1);
+#if MFCD_UVT_STAMPS
+        cyc_dma += td1 - td0;
+#endif
+        if (active) {
+#pragma unroll 1
+            for (int j = 0; j < TC / 32; ++j) {
+                const int cb = c0 + 32 * j;
+                if (cb >= c_end) continue;
+                // the tile after this one (same stage, or the first of the next stage; -1: none)
+                const int ncb = (j + 1 < TC / 32 && cb + 32 < c_end) ? cb + 32 : (c0 + TC < c_end ? c0 + TC : -1);
+                if constexpr (PFX) {
+                    if ((tile_no & 1) == 0) tile(cb, ncb, j, cms, xa, xb);
+                    else tile(cb, ncb, j, cms, xb, xa);
+                    ++tile_no;
+                } else {
+                    tile(cb, ncb, j, cms, xa, xb);
+                }
             }
         }
         MFCD_STAMP(ts0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage have landed
+        // this wave's pieces of the next stage have landed: everything but the X prefetch of the stage's last tile,
+        // which is younger than the DMA (vmcnt counts in issue order) and must stay in flight across the barrier
+        if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (pend == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // ... and everybody's; this buffer may be overwritten
         MFCD_STAMP(ts1);
 #if MFCD_UVT_STAMPS
@@ -593,13 +693,20 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     // a row's columns are split over the two lane halves
     sac += __shfl_xor(sac, 32, MFCD_WAVE);
     saa += __shfl_xor(saa, 32, MFCD_WAVE);
+    ssa += __shfl_xor(ssa, 32, MFCD_WAVE);
+    ssc += __shfl_xor(ssc, 32, MFCD_WAVE);
+    sscc += __shfl_xor(sscc, 32, MFCD_WAVE);
     if (!rowok) err2 = 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off, MFCD_WAVE);
-    if (half == 0 && rowok) {
-        double *o = part_rows + ((size_t)split * n + row0 + l31) * 2;
+    if (half == 0 && rowok) {   // kTiledRowSums doubles per (split, row): sum a c', sum a a, sum a, sum c', sum c'c', x0
+        double *o = part_rows + ((size_t)split * n + row0 + l31) * kTiledRowSums;
         o[0] = sac;
         o[1] = saa;
+        o[2] = ssa;
+        o[3] = ssc;
+        o[4] = sscc;
+        o[5] = (double)x0v;
     }
     if (lane == 0) part_err[(size_t)split * ((n + 31) / 32) + rt] = err2;
 }
@@ -644,6 +751,74 @@ __global__ __launch_bounds__(256) void uvt_final_kernel(const double *__restrict
     if (threadIdx.x == 0) {
         blk[2 * blockIdx.x + 0] = red[0][0];
         blk[2 * blockIdx.x + 1] = red[1][0];
+    }
+}
+
+// The tiled kernel's per-(split, row) sums are relative to the split's shift x0 (and to nothing for U V^T): this
+// kernel re-centres them in f64 and writes the same row_stats / block shares as uvt_final_kernel.  Per split s with
+// n_s columns and c' = x - x0_s:  sum x = S_c' + n_s x0;  sum x^2 = S_c'c' + 2 x0 S_c' + n_s x0^2;  with the fp32-rounded
+// row mean xm the reference centres with (structure.py:987) and t = xm - x0_s:
+//   sum (x - xm)^2 = S_c'c' - 2 t S_c' + n_s t^2        sum a (x - xm) = S_ac' - t S_a
+// scal != nullptr: ONE workgroup does all rows and writes the two global sums itself (small n: saves a launch).
+__global__ __launch_bounds__(1024) void uvt_final_tiled_kernel(const double *__restrict__ part_rows,
+                                                              const double *__restrict__ part_err,
+                                                              const float *__restrict__ rm, int n, int m, int splits,
+                                                              int cols_per_split, int n_err,
+                                                              double *__restrict__ row_stats, double *__restrict__ blk,
+                                                              double s, double *__restrict__ scal)
+{
+    __shared__ double red[2][1024];
+    const int nthr = blockDim.x;   // 256 (one workgroup per 256 rows) or 1024 (single-workgroup form)
+    double q = 0.0, e = 0.0;
+    for (int r = blockIdx.x * nthr + threadIdx.x; r < n; r += gridDim.x * nthr) {
+        double sx = 0.0;
+        for (int sp = 0; sp < splits; ++sp) {
+            const double *t = part_rows + ((size_t)sp * n + r) * kTiledRowSums;
+            const int c0 = sp * cols_per_split;
+            const double ns = (double)(min(m, c0 + cols_per_split) - c0);
+            sx += t[3] + ns * t[5];
+        }
+        const float xmean = (float)(sx / (double)m);
+        const double mu = (double)xmean;
+        double ac = 0.0, aa = 0.0, cc = 0.0, qr = 0.0;
+        for (int sp = 0; sp < splits; ++sp) {
+            const double *t = part_rows + ((size_t)sp * n + r) * kTiledRowSums;
+            const int c0 = sp * cols_per_split;
+            const double ns = (double)(min(m, c0 + cols_per_split) - c0);
+            const double x0 = t[5], sh = mu - x0;
+            ac += t[0] - sh * t[2];
+            aa += t[1];
+            cc += t[4] - 2.0 * sh * t[3] + ns * sh * sh;
+            qr += t[4] + 2.0 * x0 * t[3] + ns * x0 * x0;
+        }
+        double *o = row_stats + (size_t)r * 8;
+        o[0] = ac; o[1] = aa; o[2] = fmax(0.0, cc); o[3] = (double)rm[r]; o[4] = mu;
+        o[5] = qr; o[6] = 0.0; o[7] = 0.0;
+        q += qr;
+    }
+    const int per = (n_err + gridDim.x - 1) / gridDim.x;
+    const int k1 = min(n_err, ((int)blockIdx.x + 1) * per);
+    for (int k = blockIdx.x * per + threadIdx.x; k < k1; k += nthr) e += part_err[k];
+    red[0][threadIdx.x] = e;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int w = nthr >> 1; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (scal) {
+            scal[0] = red[0][0];
+            scal[1] = s * s * red[1][0];  // ||sX||_F^2  (structure.py:946)
+            scal[2] = 0.0;
+            scal[3] = 0.0;
+        } else {
+            blk[2 * blockIdx.x + 0] = red[0][0];
+            blk[2 * blockIdx.x + 1] = red[1][0];
+        }
     }
 }
 
@@ -697,6 +872,7 @@ struct UvtWs {
     float *rm, *cm, *xm;
     double *scc, *sxx, *part_rows, *part_err, *blk;
     int splits, cols_per_split, n_err, nblk;
+    bool tiled;
     size_t bytes;
 };
 
@@ -750,6 +926,7 @@ UvtWs plan_ws(char *base, int n, int m, int d)
         w.cols_per_split = ((ctiles + splits - 1) / splits) * 32;
         w.splits = (m + w.cols_per_split - 1) / w.cols_per_split;
     }
+    w.tiled = tc.NW != 0;
     w.n_err = w.splits * rtiles;
     w.nblk = (n + 255) / 256;
     size_t off = 0;
@@ -761,29 +938,40 @@ UvtWs plan_ws(char *base, int n, int m, int d)
     w.xm = (float *)take(sizeof(float) * (size_t)n);
     w.scc = (double *)take(sizeof(double) * (size_t)n);
     w.sxx = (double *)take(sizeof(double) * (size_t)n);
-    w.part_rows = (double *)take(sizeof(double) * 2 * (size_t)n * w.splits);
+    w.part_rows = (double *)take(sizeof(double) * (w.tiled ? kTiledRowSums : 2) * (size_t)n * w.splits);
     w.part_err = (double *)take(sizeof(double) * (size_t)w.n_err);
     w.blk = (double *)take(sizeof(double) * 2 * (size_t)w.nblk);
     w.bytes = off;
     return w;
 }
 
-template <int DD, int NW, int TC>
+int g_uvt_wpe128 = 2;   // mfcd_set_tuning(MFCD_TUNE_UVT_WPE128): 2 = X prefetch at 2 waves/SIMD (default), 3 = round-1 form
+
+template <int DD, int NW, int TC, int WPE = 2, bool PFX = (DD <= 128)>
 int launch_tiled(const UvtWs &w, const float *U, const float *V, const float *X, int n, int m, float s, bool xv,
                  hipStream_t st)
 {
     const int row_blocks = (n + NW * 32 - 1) / (NW * 32);
     const unsigned blocks = (unsigned)row_blocks * (w.splits >= 8 ? 8u * ((w.splits + 7) / 8) : (unsigned)w.splits);
     if (xv)
-        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
-                           w.cm, w.xm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
+        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, WPE, PFX>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
+                           w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
     else
-        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, false>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
-                           w.cm, w.xm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
+        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, false, WPE, PFX>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
+                           w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
     return 0;
 }
 
 }  // namespace
+
+namespace mfcd_detail {
+int set_uvt_wpe128(int v)
+{
+    if (v != 2 && v != 3) return MFCD_EINVAL;
+    g_uvt_wpe128 = v;
+    return 0;
+}
+}  // namespace mfcd_detail
 
 extern "C" size_t mfcd_uvt_workspace_bytes(int n, int m, int d)
 {
@@ -800,32 +988,56 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
     if (workspace_bytes < w.bytes) return MFCD_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool xv = (reinterpret_cast<uintptr_t>(X) & 15u) == 0 && m % 4 == 0;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(kSlices, 2), dim3(256), 0, st, U, V, n, m, d, w.colpart);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256, 2), dim3(256), 0, st, w.colpart, n, m, d, w.bar);
-    hipLaunchKernelGGL(centre_vectors_kernel, dim3((unsigned)(((int64_t)n + m + 3) / 4)), dim3(256), 0, st, U, V,
-                       w.bar, n, m, d, w.rm, w.cm);
-    if (xv) hipLaunchKernelGGL(x_rows_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
-    else hipLaunchKernelGGL(x_rows_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
-    const dim3 grid(((n + 31) / 32 + 3) / 4, w.splits);
     const bool al16 = ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15u) == 0;
-    const TiledCfg tc = n >= 32 && (int64_t)m * d < (int64_t)0x7fff0000 ? tiled_cfg(d) : TiledCfg{0, 0};
+    // fused form: X read ONCE, 5 launches (round 1: 8 launches, X read twice); tables off a 16-byte boundary take the
+    // generic form (the plan's column split suits both)
+    const bool tiled = w.tiled && al16;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(slices_for(n > m ? n : m), 2), dim3(256), 0, st, U, V, n, m, d,
+                       w.colpart);
+    {   // 16 rows per workgroup (4 per wave).  Small tables: every workgroup reduces the few partial sums itself
+        // (one launch less); large ones: one small kernel reduces them once.
+        const int64_t rows = (int64_t)n + m;
+        const bool merged = (int64_t)(slices_for(n) + slices_for(m)) * d <= 8192;
+        if (!merged)
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256, 2), dim3(256), 0, st, w.colpart, n, m, d, w.bar);
+        const int rpb = 16;
+        hipLaunchKernelGGL(centre_vectors_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
+                           sizeof(float) * 2 * (size_t)d, st, U, V, w.colpart, merged ? (const float *)nullptr : w.bar, n,
+                           m, d, rpb, w.rm, w.cm);
+    }
+    if (tiled) {
+        if (d == 256) { const int rc = launch_tiled<256, 4, 32>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+        else if (d == 128 && g_uvt_wpe128 == 3) { const int rc = launch_tiled<128, 4, 32, 3, false>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+        else if (d == 128) { const int rc = launch_tiled<128, 4, 32, 2, true>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+        else if (d == 64) { const int rc = launch_tiled<64, 4, 64>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+        else { const int rc = launch_tiled<32, 4, 128>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+        if (n <= 8192) {   // small n: one workgroup finishes the rows AND the two global sums
+            hipLaunchKernelGGL(uvt_final_tiled_kernel, dim3(1), dim3(1024), 0, st, w.part_rows, w.part_err, w.rm, n, m,
+                               w.splits, w.cols_per_split, w.n_err, row_stats, w.blk, s, scal);
+            MFCD_HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        hipLaunchKernelGGL(uvt_final_tiled_kernel, dim3(w.nblk), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, n, m,
+                           w.splits, w.cols_per_split, w.n_err, row_stats, w.blk, s, (double *)nullptr);
+    } else {
+        // generic form (any d, tables of fewer than 32 rows): X row statistics from a sweep of their own
+        if (xv) hipLaunchKernelGGL(x_rows_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
+        else hipLaunchKernelGGL(x_rows_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
+        const dim3 grid(((n + 31) / 32 + 3) / 4, w.splits);
 #define MFCD_UVT(DD)                                                                                            \
     hipLaunchKernelGGL((uvt_main_kernel<DD>), grid, dim3(256), 0, st, U, V, X, w.rm, w.cm, w.xm, n, m, d, (float)s, \
                        w.cols_per_split, w.part_rows, w.part_err)
-    if (al16 && tc.NW && d == 256) { const int rc = launch_tiled<256, 4, 32>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-    else if (al16 && tc.NW && d == 128) { const int rc = launch_tiled<128, 4, 32>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-    else if (al16 && tc.NW && d == 64) { const int rc = launch_tiled<64, 4, 64>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-    else if (al16 && tc.NW && d == 32) { const int rc = launch_tiled<32, 4, 128>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-    else if (al16 && d == 8) MFCD_UVT(8);
-    else if (al16 && d == 16) MFCD_UVT(16);
-    else if (al16 && d == 32) MFCD_UVT(32);
-    else if (al16 && d == 64) MFCD_UVT(64);
-    else if (al16 && d == 128) MFCD_UVT(128);
-    else if (al16 && d == 256) MFCD_UVT(256);
-    else MFCD_UVT(0);
+        if (al16 && d == 8) MFCD_UVT(8);
+        else if (al16 && d == 16) MFCD_UVT(16);
+        else if (al16 && d == 32) MFCD_UVT(32);
+        else if (al16 && d == 64) MFCD_UVT(64);
+        else if (al16 && d == 128) MFCD_UVT(128);
+        else if (al16 && d == 256) MFCD_UVT(256);
+        else MFCD_UVT(0);
 #undef MFCD_UVT
-    hipLaunchKernelGGL(uvt_final_kernel, dim3(w.nblk), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, w.xm, w.scc,
-                       w.sxx, n, w.splits, w.n_err, row_stats, w.blk);
+        hipLaunchKernelGGL(uvt_final_kernel, dim3(w.nblk), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, w.xm,
+                           w.scc, w.sxx, n, w.splits, w.n_err, row_stats, w.blk);
+    }
     hipLaunchKernelGGL(uvt_scal_kernel, dim3(1), dim3(256), 0, st, w.blk, w.nblk, s, scal);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;

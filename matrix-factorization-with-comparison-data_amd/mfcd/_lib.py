@@ -41,13 +41,23 @@ SIGNATURES = {
     "mfcd_dp_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _i32]),
     "mfcd_dp_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
                             [_vp, _vp, _sz, _vp, _vp]),
+    "mfcd_shard_rows": (_i32, [_i32, _i32, _i32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mfcd_shard_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "mfcd_shard_pack": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mfcd_shard_apply": (_i32, [_vp] * 7 + [_i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp]),
+    "mfcd_shard_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
+                               [_vp, _vp, _sz, _vp, _vp]),
     "mfcd_uvt_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mfcd_uvt_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_uvt_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mfcd_generate_labels": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _dbl, _i32, _i32, ctypes.c_uint64, _vp,
+                                     _vp]),
+    "mfcd_spearman_max_columns": (_i32, []),
+    "mfcd_spearman_rows": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
 }
 
 TUNE_KEYS = {"resident_q": 1, "resident_wpc": 2, "resident_lookahead": 3, "resident_lds_pad": 4,
-             "resident_spin_limit": 5, "short_call_steps": 6}
+             "resident_spin_limit": 5, "short_call_steps": 6, "uvt_wpe128": 7}
 
 
 class TrainPlan(ctypes.Structure):

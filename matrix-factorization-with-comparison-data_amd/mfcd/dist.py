@@ -110,19 +110,7 @@ class NativeDP:
             self.rank, self.world = 0, int(simulate_world)
         else:
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-            uid = torch.zeros(self.ID_BYTES, dtype=torch.uint8)
-            if self.rank == 0:
-                buf = (ctypes.c_ubyte * self.ID_BYTES)()
-                _lib.check(self.L.mfcd_dp_unique_id(ctypes.cast(buf, ctypes.c_void_p), self.ID_BYTES))
-                uid = torch.tensor(list(buf), dtype=torch.uint8)
-            backend = dist.get_backend(group)
-            carrier = uid.to(self.dev) if backend == "nccl" else uid
-            dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            raw = bytes(carrier.cpu().tolist())
-            handle = ctypes.c_void_p()
-            with torch.cuda.device(self.dev):
-                _lib.check(self.L.mfcd_dp_comm_create(raw, self.ID_BYTES, self.rank, self.world, ctypes.byref(handle)))
-            self.comm = handle
+            self.comm = create_native_comm(self.L, self.dev, self.rank, self.world, group)
         self.ws = None
 
     def close(self):
@@ -150,6 +138,156 @@ class NativeDP:
             _lib.ptr(loss_out), _lib.ptr(self.ws), self.ws.numel(), self.comm, _lib.stream_ptr(self.dev)))
         self.b.advance(nsteps)
         return loss_out[:nsteps]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Row-sharded state: strong scaling at the reference's batch size (include/mfcd.h: mfcd_shard_*)
+# ---------------------------------------------------------------------------------------------------------------
+def shard_rows(rows, rank, world):
+    """Rows [lo, hi) of a `rows`-row table that rank `rank` of `world` owns (contiguous, sizes differ by at most 1)."""
+    return rows * rank // world, rows * (rank + 1) // world
+
+
+class RowShard:
+    """This rank's rows of U, V and of their Adam moments, cut out of full tensors (and written back by `gather`)."""
+
+    def __init__(self, binding, rank, world):
+        self.b, self.rank, self.world = binding, rank, world
+        U, V, mU, vU, mV, vV = binding.tensors()
+        self.n, self.d, self.m = U.shape[0], U.shape[1], V.shape[0]
+        self.u_lo, self.u_hi = shard_rows(self.n, rank, world)
+        self.v_lo, self.v_hi = shard_rows(self.m, rank, world)
+        cut = lambda t, lo, hi: t[lo:hi].clone().contiguous()          # noqa: E731
+        self.U, self.mU, self.vU = (cut(t, self.u_lo, self.u_hi) for t in (U, mU, vU))
+        self.V, self.mV, self.vV = (cut(t, self.v_lo, self.v_hi) for t in (V, mV, vV))
+
+    def tensors(self):
+        return self.U, self.V, self.mU, self.vU, self.mV, self.vV
+
+    def gather(self, group=None):
+        """All-gather the shards back into the binding's full tensors (every rank ends with the whole model)."""
+        full = self.b.tensors()
+        for part, whole, rows in zip(self.tensors(), full, (self.n, self.m, self.n, self.n, self.m, self.m)):
+            sizes = [shard_rows(rows, r, self.world) for r in range(self.world)]
+            pieces = [torch.empty((hi - lo, self.d), dtype=whole.dtype, device=whole.device) for lo, hi in sizes]
+            dist.all_gather(pieces, part, group=group)
+            for (lo, hi), piece in zip(sizes, pieces):
+                whole[lo:hi] = piece
+
+
+class HipShardCompute:
+    """C-ABI backed halves of one row-sharded optimiser step (device tensors only)."""
+
+    def __init__(self, shard):
+        self.s, self.L = shard, _lib.load()
+        self.dev = shard.U.device
+
+    def new_xbuf(self, B):
+        return torch.empty(3 * B * self.s.d, dtype=torch.float32, device=self.dev)
+
+    def pack(self, batch, B, xbuf):
+        s = self.s
+        _lib.check(self.L.mfcd_shard_pack(_lib.ptr(s.U) if s.U.numel() else None, _lib.ptr(s.V) if s.V.numel() else None,
+                                          _lib.ptr(batch), batch.shape[0], B, s.d, s.u_lo, s.u_hi, s.v_lo, s.v_hi,
+                                          _lib.ptr(xbuf), _lib.stream_ptr(self.dev)))
+
+    def apply(self, batch, B, xbuf, step, hyper, terms):
+        s = self.s
+        p = lambda t: _lib.ptr(t) if t.numel() else None              # noqa: E731
+        lr, b1, b2, eps, wd = hyper
+        _lib.check(self.L.mfcd_shard_apply(p(s.U), p(s.V), p(s.mU), p(s.vU), p(s.mV), p(s.vV), _lib.ptr(batch),
+                                           batch.shape[0], B, _lib.ptr(xbuf), step, s.d, s.u_lo, s.u_hi, s.v_lo,
+                                           s.v_hi, lr, b1, b2, eps, wd, _lib.ptr(terms), _lib.stream_ptr(self.dev)))
+
+
+def train_steps_sharded(compute, stream, B, step0, hyper, group=None):
+    """Consume `stream` (int32 [N,4] records, identical on every rank) in batches of B — the reference's batch, NOT
+    B*world — with the state sharded by rows over the group.  Per step: pack the owned rows of the batch, ONE
+    all-reduce(sum) of the exchange buffer viewed as int32 (exact: one non-zero contributor per row), apply.
+    Returns the fp32 tensor of per-step batch-mean losses (identical on every rank; no collective needed for them:
+    every rank holds every sample's rows).  `compute` provides new_xbuf / pack / apply (HipShardCompute; the CPU tests
+    inject an oracle-backed one)."""
+    N = stream.shape[0]
+    nsteps = (N + B - 1) // B
+    losses = torch.empty(nsteps, dtype=torch.float32, device=stream.device)
+    xbuf = compute.new_xbuf(B)
+    terms = torch.empty(B, dtype=torch.float32, device=stream.device)
+    for k in range(nsteps):
+        batch = stream[k * B:(k + 1) * B]
+        compute.pack(batch, B, xbuf)
+        dist.all_reduce(xbuf.view(torch.int32), op=dist.ReduceOp.SUM, group=group)
+        compute.apply(batch, B, xbuf, step0 + k + 1, hyper, terms)
+        losses[k] = terms[: batch.shape[0]].sum() / batch.shape[0]   # ~1 ulp of the native loop's fixed-order mean
+    return losses
+
+
+class NativeShard:
+    """Row-sharded optimiser steps through the native loop (include/mfcd.h: mfcd_shard_train_steps): the per-step
+    pack → ncclAllReduce → fused step chain is enqueued inside libmfcd_hip.so.  With `simulate_world` (no group) the
+    tensors stay whole and the library plays every rank in this process: the single-process rehearsal."""
+
+    def __init__(self, binding, group=None, simulate_world=None):
+        self.b, self.L = binding, _lib.load()
+        U, V = binding.model.U.data, binding.model.V.data
+        if U.dtype != torch.float32:
+            raise NotImplementedError("the row-sharded loop takes fp32 factors")
+        self.n, self.d, self.m, self.dev = U.shape[0], U.shape[1], V.shape[0], U.device
+        self.comm, self.shard, self.group = None, None, group
+        if simulate_world is not None:
+            self.rank, self.world = 0, int(simulate_world)
+        else:
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            self.comm = create_native_comm(self.L, self.dev, self.rank, self.world, group)
+            self.shard = RowShard(binding, self.rank, self.world)
+        self.ws = None
+
+    def close(self):
+        if self.comm is not None:
+            torch.cuda.synchronize(self.dev)
+            _lib.check(self.L.mfcd_dp_comm_destroy(self.comm))
+            self.comm = None
+
+    def train_steps(self, stream, B, loss_out=None):
+        N = stream.shape[0]
+        nsteps = (N + B - 1) // B
+        if loss_out is None:
+            loss_out = torch.empty(max(nsteps, 1), dtype=torch.float32, device=self.dev)
+        need = self.L.mfcd_shard_workspace_bytes(N, B, self.d)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(int(need), dtype=torch.uint8, device=self.dev)
+        tens = self.shard.tensors() if self.shard is not None else self.b.tensors()
+        p = lambda t: _lib.ptr(t) if t.numel() else _lib.ptr(self.ws)   # noqa: E731  (an empty shard is never dereferenced)
+        lr, b1, b2, eps, wd = self.b.hyper()
+        _lib.check(self.L.mfcd_shard_train_steps(*[p(t) for t in tens], _lib.ptr(stream), N, B, self.rank, self.world,
+                                                 self.b.step, self.n, self.m, self.d, lr, b1, b2, eps, wd,
+                                                 _lib.ptr(loss_out), _lib.ptr(self.ws), self.ws.numel(), self.comm,
+                                                 _lib.stream_ptr(self.dev)))
+        self.b.advance(nsteps)
+        return loss_out[:nsteps]
+
+    def gather(self):
+        if self.shard is not None:
+            self.shard.gather(self.group)
+
+
+def create_native_comm(L, dev, rank, world, group=None):
+    """RCCL communicator inside libmfcd_hip.so for this rank: rank 0 draws the ncclUniqueId, the caller's
+    torch.distributed group carries it."""
+    import ctypes
+    nbytes = NativeDP.ID_BYTES
+    uid = torch.zeros(nbytes, dtype=torch.uint8)
+    if rank == 0:
+        buf = (ctypes.c_ubyte * nbytes)()
+        _lib.check(L.mfcd_dp_unique_id(ctypes.cast(buf, ctypes.c_void_p), nbytes))
+        uid = torch.tensor(list(buf), dtype=torch.uint8)
+    backend = dist.get_backend(group)
+    carrier = uid.to(dev) if backend == "nccl" else uid
+    dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    raw = bytes(carrier.cpu().tolist())
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        _lib.check(L.mfcd_dp_comm_create(raw, nbytes, rank, world, ctypes.byref(handle)))
+    return handle
 
 
 def shard_bounds(global_lo, global_hi, batch_local, rank):
@@ -232,6 +370,7 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
     binding = engine.AdamBinding(model, opt)
     broadcast_state(binding)
     native = None
+    sharded = mode == "shard"
     if mode == "native":
         # RCCL not loadable inside the library is the same on every rank (same image, same process layout): then the
         # per-step torch.distributed loop over the same HIP kernels takes over, and the JSON line says so
@@ -241,12 +380,14 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
             if "RCCL" not in str(e):
                 raise
             mode = "allgather"
+    elif sharded:
+        native = NativeShard(binding)       # row-sharded state, batch = B (the reference's), results = one GPU's
     compute = HipCompute(binding) if native is None else None
     train = engine.SampleStore(tr, cfg["n"], cfg["m"], dev)
     val = engine.SampleStore(va, cfg["n"], cfg["m"], dev)
     gen = torch.Generator().manual_seed(seed + 1)           # same permutations on every rank
     B = cfg["B"]
-    Bg = B * world
+    Bg = B if sharded else B * world
     steps_per_epoch = (train.N + Bg - 1) // Bg
     state = {"stream": None, "pos": 0}
 
@@ -265,6 +406,8 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
             state["pos"] += take
             nsteps -= take
             if state["pos"] == steps_per_epoch:               # validation pass, sharded over ranks by batch
+                if sharded:
+                    native.gather()                           # the no-grad pass needs every row: all-gather the shards
                 vlo = (val.N * rank) // world
                 vhi = (val.N * (rank + 1)) // world
                 engine.eval_batches(model.U.data, model.V.data, val.dev[vlo:vhi], B)
@@ -281,6 +424,8 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    if sharded:
+        native.gather()
     # replicas must still agree bit for bit
     chk = torch.stack([model.U.data.double().sum(), model.V.data.double().sum()])
     lo_, hi_ = chk.clone(), chk.clone()
@@ -291,19 +436,25 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
         native.close()
     what = {"native": "native loop in libmfcd_hip.so: one in-place RCCL all-gather of 64 {g, term} pairs per rank per "
                       "optimiser step", "allgather": "torch.distributed all-gather per optimiser step",
-            "allreduce": "dense fp32 gradient all-reduce per optimiser step"}[mode]
+            "allreduce": "dense fp32 gradient all-reduce per optimiser step",
+            "shard": "row-sharded state in libmfcd_hip.so: one RCCL all-reduce of the batch's <= 192 rows per optimiser "
+                     "step, global batch 64, results equal to one GPU"}[mode]
     abytes = bench_mod.algorithmic_bytes_per_step(dict(cfg, B=Bg))
     return {
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3 / steps, 6),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
         "config": {"workload": f"{cfg.get('name', 'C2')}: n={cfg['n']} m={cfg['m']} d={cfg['d']} p={cfg['p']} K={cfg.get('K', 1)} "
-                               "random triplets, per-GPU batch 64, Adam lr=1e-3 wd=1e-5, validation pass per epoch",
+                               f"random triplets, {'global' if sharded else 'per-GPU'} batch 64, Adam lr=1e-3 wd=1e-5, "
+                               "validation pass per epoch",
                    "global_batch": Bg, "train_samples": train.N,
                    "parallelism": f"dp{world} ({what})",
                    "replicas_in_sync": in_sync},
         "roofline": {"bound": "hbm", "achieved": round(abytes / (dt / steps) / 1e9, 1), "peak": bench_mod.HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(abytes / (dt / steps) / 1e9 / bench_mod.HBM_PEAK_GBS, 4),
                      "traffic": None, "algorithmic_bytes_per_launch": abytes,
-                     "note": "per-GPU step period including the collective; every rank streams the full replicated state"},
+                     "note": ("per-GPU step period including the collective; every rank sweeps 1/world of the state"
+                              if sharded else
+                              "per-GPU step period including the collective; every rank streams the full replicated state")},
     }

@@ -76,10 +76,44 @@ class AdamBinding:
         return U, V, su["exp_avg"], su["exp_avg_sq"], sv["exp_avg"], sv["exp_avg_sq"]
 
 
+def generate_labels(triplets, X, scale=1.0, K=1, soft=False, seed=0, device=None):
+    """BTL labels drawn ON the device (include/mfcd.h: mfcd_generate_labels) → int32 [N, 4] device tensor
+    of mfcd_sample records (N = T*K hard-label rows, or T soft-label rows), ready for SampleStore / train_steps.
+    `X` is a dense [n, m] fp32 tensor (moved to the device if needed) or a generation_data.FactoredMatrix, whose n x m
+    product is never formed.  Reproducible for a seed; not the reference's CPU generator stream."""
+    L = _lib.load()
+    idx = np.ascontiguousarray(np.asarray(triplets, dtype=np.int64).reshape(-1, 3))
+    T = idx.shape[0]
+    n, m = X.shape
+    if T and (idx.min() < 0 or idx[:, 0].max() >= n or idx[:, 1:].max() >= m):
+        raise IndexError("triplet index out of range for X")          # as X[u, i] would (structure.py:509)
+    if device is None:
+        device = X.device if isinstance(X, torch.Tensor) and X.is_cuda else torch.device("cuda")
+    device = torch.device(device)
+    trip = torch.from_numpy(idx.astype(np.int32)).to(device)
+    out = torch.empty((T if soft else T * K, 4), dtype=torch.int32, device=device)
+    if isinstance(X, torch.Tensor):
+        Xd = X.detach().to(device=device, dtype=torch.float32).contiguous()
+        args = (_lib.ptr(Xd), n, m, None, None, 0)
+    else:                                                              # FactoredMatrix
+        A = X.A.to(device).contiguous()
+        B = X.B.to(device).contiguous()
+        args = (None, n, m, _lib.ptr(A), _lib.ptr(B), A.shape[1])
+    _lib.check(L.mfcd_generate_labels(_lib.ptr(trip) if T else None, T, *args, float(scale), int(K), int(bool(soft)),
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(out) if out.numel() else None,
+                                      _lib.stream_ptr(device)))
+    return out
+
+
 class SampleStore:
     """A dataset's (u,i,j,z) records resident in HBM as 16-byte mfcd_sample structs."""
 
     def __init__(self, rows, n, m, device):
+        if isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dtype == torch.int32:
+            self.dev = rows.to(device).contiguous()         # records made on the device (generate_labels): no host copy
+            self.N, self.host = self.dev.shape[0], None
+            self.device = self.dev.device
+            return
         rec = pack_records(rows, n, m)
         self.N = rec.shape[0]
         self.host = rec
@@ -95,7 +129,9 @@ class SampleStore:
         cached = getattr(ds, "_mfcd_store", None)
         if cached is not None and cached[0] == key:
             return cached[1]
-        store = cls(dataset_records(ds), n, m, device)
+        dev_fn = getattr(ds, "_mfcd_device_records", None)
+        dev_rec = dev_fn() if callable(dev_fn) else None
+        store = cls(dev_rec if dev_rec is not None else dataset_records(ds), n, m, device)
         try:
             ds._mfcd_store = (key, store)
         except AttributeError:

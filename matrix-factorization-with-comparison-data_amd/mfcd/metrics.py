@@ -4,9 +4,10 @@ The n x m product UV^T is never materialised for the Frobenius / Pearson / slope
 libmfcd_hip.so's MFMA pass returns per-row sums and two global sums (include/mfcd.h,
 mfcd_uvt_stats), and everything the reference derives from them is formed here in f64.
 
-Spearman correlations and the singular-value error (structure.py:1011-1031) are SURVEY §8f row N4
-("next"): until they get their own kernels they run as torch ops on the same GPU (sort-based ranks,
-svdvals); they are not part of the hot-path parity claim.
+Spearman correlations (structure.py:1023-1031) run on the HIP rank kernel
+(mfcd_spearman_rows: bitonic sort in LDS, exact integer rank sums) over rows of U V^T formed by a plain
+library GEMM.  The singular-value error (structure.py:1011-1017) stays on torch's dense eigen-solver: U V^T
+has rank <= d, so its spectrum comes from a d x d problem, and X's spectrum is cached per X.
 """
 import numpy as np
 import torch
@@ -82,14 +83,57 @@ def _rank_rows(M):
     return ranks
 
 
+def spearman_rows(A, X):
+    """Per-row Spearman rho of two [rows, m] fp32 GPU matrices (rows may be strided views) → f64 [rows] on device.
+    HIP kernel (include/mfcd.h: mfcd_spearman_rows), m <= 16384."""
+    L = _lib.load()
+    rows, m = A.shape
+    if X.shape != A.shape or A.dtype != torch.float32 or X.dtype != torch.float32 or not A.is_cuda or not X.is_cuda:
+        raise _lib.MfcdError("spearman_rows needs two float32 GPU matrices of the same shape")
+    if A.stride(1) != 1 or X.stride(1) != 1:
+        A, X = A.contiguous(), X.contiguous()
+    rho = torch.empty(rows, dtype=torch.float64, device=A.device)
+    _lib.check(L.mfcd_spearman_rows(A.data_ptr(), A.stride(0) if rows > 1 else m, X.data_ptr(),
+                                    X.stride(0) if rows > 1 else m, rows, m, _lib.ptr(rho),
+                                    _lib.stream_ptr(A.device)))
+    return rho
+
+
+_x_spectrum_cache = {}
+
+
+def _x_singular_values(X, xmean):
+    """Singular values of the row-centred X from the Gram matrix on its smaller side (f64): same spectrum as
+    torch.linalg.svd(X) to ~4e-8 relative at C2 and 40x cheaper than svdvals (118 ms vs 4.6 s at 4096^2).
+    X is constant while a model trains and is evaluated against it, so the spectrum is cached per X (keyed by
+    storage address, shape and in-place version counter)."""
+    key = (X.data_ptr(), tuple(X.shape), X._version, str(X.device))
+    hit = _x_spectrum_cache.get(key)
+    if hit is not None:
+        return hit
+    n, m = X.shape
+    Xc = (X - xmean[:, None]).double()
+    G = Xc @ Xc.t() if n <= m else Xc.t() @ Xc
+    s1 = torch.sqrt(torch.clamp(torch.linalg.eigvalsh(G), min=0.0)).flip(0)
+    _x_spectrum_cache.clear()            # one X at a time
+    _x_spectrum_cache[key] = s1
+    return s1
+
+
 def spearman_and_svd(U, V, X_centred_rows_mean, X, alpha, ok_rows, row_block=2048):
-    """N4 ("next") rows on torch-GPU ops: per-row Spearman rho and the singular-value error."""
+    """per-row Spearman rho (HIP rank kernel on rows of U V^T formed by a plain library GEMM; torch
+    sort-based ranks only for rows longer than the kernel's 16384 columns) and the singular-value error."""
     n, m = X.shape
     rho = torch.empty(n, dtype=torch.float64, device=X.device)
     vbar = V.mean(dim=0, keepdim=True)
+    Vc = V - vbar
+    in_kernel = m <= _lib.load().mfcd_spearman_max_columns()
     for r0 in range(0, n, row_block):
         r1 = min(n, r0 + row_block)
-        A = U[r0:r1] @ (V - vbar).t()                      # row-centred UV^T block (ranks ignore the shift)
+        A = U[r0:r1] @ Vc.t()                              # row-centred UV^T block (ranks ignore the shift)
+        if in_kernel:
+            rho[r0:r1] = spearman_rows(A, X[r0:r1])
+            continue
         ra, rx = _rank_rows(A), _rank_rows(X[r0:r1])
         ra = ra - ra.mean(1, keepdim=True)
         rx = rx - rx.mean(1, keepdim=True)
@@ -98,13 +142,8 @@ def spearman_and_svd(U, V, X_centred_rows_mean, X, alpha, ok_rows, row_block=204
     scores = [np.float64(r) for r, o in zip(rho, ok_rows) if o and not np.isnan(r)]  # spearmanr yields np.float64
     # singular values: X centred (n x m); UV^T centred has rank <= d -> spectrum from a d x d problem
     try:
-        # singular values of the row-centred X from the Gram matrix on its smaller side (f64): same spectrum as
-        # torch.linalg.svd(X) to ~4e-8 relative at C2 and 40x cheaper than svdvals (118 ms vs 4.6 s at 4096^2)
-        Xc = (X - X_centred_rows_mean[:, None]).double()
-        G = Xc @ Xc.t() if n <= m else Xc.t() @ Xc
-        s1 = torch.sqrt(torch.clamp(torch.linalg.eigvalsh(G), min=0.0)).flip(0)
-        del G, Xc
-        Vc = (V - vbar).double()
+        s1 = _x_singular_values(X, X_centred_rows_mean)
+        Vc = Vc.double()
         # sigma(U Vc^T) = sqrt(eig( (U^T U)^{1/2} (Vc^T Vc) (U^T U)^{1/2} )) ; use QR-free form via svdvals of R factors
         Ru = torch.linalg.qr(U.double(), mode="r").R
         Rv = torch.linalg.qr(Vc, mode="r").R

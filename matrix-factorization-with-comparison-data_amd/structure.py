@@ -121,6 +121,18 @@ def compute_ground_truth_metrics(test_loader, X, device):
 # ------------------------------------------------------------------------------------------------
 # data (ref:465-742)
 # ------------------------------------------------------------------------------------------------
+_LABEL_DEVICE = None
+
+
+def set_label_device(device):
+    """Extension (not in the reference): draw BTL labels on `device` (a GPU) from now on; None (default) restores the
+    host path, which consumes torch's CPU generator exactly like the reference."""
+    global _LABEL_DEVICE
+    if device is not None:
+        _need_gpu(device)
+    _LABEL_DEVICE = None if device is None else torch.device(device)
+
+
 class BTLPreferenceDataset(Dataset):
     """ref:465-531.  `.data` is a list of (u, i, j, label) tuples.  Labels are drawn with ONE
     vectorised torch.bernoulli call over all rows, which consumes the CPU generator exactly like the
@@ -131,9 +143,21 @@ class BTLPreferenceDataset(Dataset):
     the source of truth (callers may edit or replace it, as they can with the reference's)."""
 
     def __init__(self, triplets, X, scale=1.0, K=1, soft_label=False, train=False):
+        """With `set_label_device(device)` in force (extension; off by default) the labels are drawn and the records
+        built ON that GPU (mfcd_generate_labels) — same law per label, Philox stream keyed by one int64
+        taken from torch's global generator instead of the CPU Mersenne-Twister stream, so runs are reproducible but
+        not bit-comparable with the reference; nothing of the dataset touches host memory unless `.data` is read."""
         self.X, self.scale, self.soft_label = X, scale, soft_label
-        self._rows = self._label_rows(triplets, K, train)
         self._data = None
+        self._dev = None
+        device_labels = _LABEL_DEVICE
+        if device_labels is not None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            self._dev = _engine.generate_labels(triplets, X, scale=scale, K=K, soft=bool(soft_label and train),
+                                                seed=seed, device=device_labels)
+            self._rows = None
+            return
+        self._rows = self._label_rows(triplets, K, train)
 
     def _label_rows(self, triplets, K, train):
         idx = np.asarray(list(triplets) if not isinstance(triplets, (list, np.ndarray)) else triplets,
@@ -171,12 +195,22 @@ class BTLPreferenceDataset(Dataset):
 
     def _mfcd_records(self):
         """float64 [N, 4] rows for the device path, or None once `.data` has been handed out."""
+        if self._rows is None and self._dev is not None and self._data is None:
+            rec = self._dev.cpu().numpy()
+            rows = np.empty((rec.shape[0], 4), dtype=np.float64)
+            rows[:, :3] = rec[:, :3]
+            rows[:, 3] = rec[:, 3].copy().view(np.float32)
+            self._rows = rows
         return self._rows
+
+    def _mfcd_device_records(self):
+        """int32 [N, 4] device records when the labels were drawn on the device and `.data` was never handed out."""
+        return self._dev if self._data is None else None
 
     @property
     def data(self):
         if self._data is None:
-            self._data, self._rows = self._tuples(self._rows), None
+            self._data, self._rows = self._tuples(self._mfcd_records()), None
         return self._data
 
     @data.setter
@@ -184,12 +218,14 @@ class BTLPreferenceDataset(Dataset):
         self._data, self._rows = value, None
 
     def __len__(self):
-        return self._rows.shape[0] if self._rows is not None else len(self._data)
+        if self._data is not None:
+            return len(self._data)
+        return self._rows.shape[0] if self._rows is not None else self._dev.shape[0]
 
     def __getitem__(self, idx):
-        if self._rows is None:
+        if self._data is not None:
             return self._data[idx]
-        r = self._rows[idx]
+        r = self._mfcd_records()[idx]
         return (int(r[0]), int(r[1]), int(r[2]), float(r[3]))
 
 

@@ -179,6 +179,16 @@ def _rankdata_rows(a):
     return rankdata(a, axis=1)
 
 
+def spearman_rows(A, X):
+    """structure.py:1023-1031 per row: scipy.stats.spearmanr(a, x).correlation = Pearson correlation of the average
+    ranks, float64.  NaN for a constant row (scipy warns and returns nan)."""
+    ra, rx = _rankdata_rows(np.asarray(A)), _rankdata_rows(np.asarray(X))
+    ra = ra - ra.mean(1, keepdims=True)
+    rx = rx - rx.mean(1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.sum(ra * rx, 1) / np.sqrt(np.sum(ra * ra, 1) * np.sum(rx * rx, 1))
+
+
 def alpha_and_norm_ratios(U, V, X_init):
     """structure.py:958-1082 → the same 14-tuple (lists hold Python/NumPy floats)."""
     UVT = _f32(U) @ _f32(V).T                                            # 982

@@ -136,3 +136,137 @@ def test_shard_bounds_cover_each_global_batch_once():
             assert lo <= a <= b <= hi and b - a <= B
             seen += list(range(a, b))
         assert seen == list(range(lo, min(hi, lo + B * world)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# row-sharded state (mfcd.dist.train_steps_sharded): gloo, world 2, oracle-backed halves
+# ---------------------------------------------------------------------------------------------------------------
+class OracleShardCompute:
+    """Oracle-backed stand-in for mfcd.dist.HipShardCompute: this rank's rows of U, V and of the moments as numpy."""
+
+    def __init__(self, U0, V0, rank, world, lr, wd):
+        from oracle import oracle as O
+        from mfcd.dist import shard_rows
+        self.orc = O.COracle()
+        (n, self.d), m = U0.shape, V0.shape[0]
+        self.u_lo, self.u_hi = shard_rows(n, rank, world)
+        self.v_lo, self.v_hi = shard_rows(m, rank, world)
+        self.U, self.V = U0[self.u_lo:self.u_hi].copy(), V0[self.v_lo:self.v_hi].copy()
+        self.mU, self.vU = np.zeros_like(self.U), np.zeros_like(self.U)
+        self.mV, self.vV = np.zeros_like(self.V), np.zeros_like(self.V)
+        self.lr, self.wd = lr, wd
+
+    def new_xbuf(self, B):
+        return torch.zeros(3 * B * self.d, dtype=torch.float32)
+
+    def pack(self, batch, B, xbuf):
+        x = xbuf.numpy().reshape(3, B, self.d)
+        x[:] = 0.0
+        r = batch.numpy()
+        for t in range(r.shape[0]):
+            u, i, j = int(r[t, 0]), int(r[t, 1]), int(r[t, 2])
+            if self.u_lo <= u < self.u_hi:
+                x[0, t] = self.U[u - self.u_lo]
+            if self.v_lo <= i < self.v_hi:
+                x[1, t] = self.V[i - self.v_lo]
+            if self.v_lo <= j < self.v_hi:
+                x[2, t] = self.V[j - self.v_lo]
+
+    def apply(self, batch, B, xbuf, step, hyper, terms):
+        x = xbuf.numpy().reshape(3, B, self.d)
+        r = batch.numpy()
+        Bk = r.shape[0]
+        z = r[:, 3].copy().view(np.float32)
+        # forward on the gathered rows (a Bk x d "table" per role, sample t in row t)
+        idx = np.arange(Bk)
+        p, term = self.orc.forward(np.ascontiguousarray(x[0, :Bk]), np.ascontiguousarray(np.concatenate([x[1, :Bk], x[2, :Bk]])),
+                                   idx, idx, idx + Bk, z)
+        one = np.float32(1.0)
+        den = np.maximum((one - p) * p, np.float32(1e-12))
+        g = ((np.float32(1.0 / Bk) * (p - z) / den).astype(np.float32) * (one - p) * p).astype(np.float32)
+        dU, dV = np.zeros_like(self.U), np.zeros_like(self.V)
+        for t in range(Bk):
+            u, i, j = int(r[t, 0]), int(r[t, 1]), int(r[t, 2])
+            if self.u_lo <= u < self.u_hi:
+                dU[u - self.u_lo] += g[t] * (x[1, t] - x[2, t])
+            if self.v_lo <= i < self.v_hi:
+                dV[i - self.v_lo] += g[t] * x[0, t]
+            if self.v_lo <= j < self.v_hi:
+                dV[j - self.v_lo] += -(g[t] * x[0, t])
+        lr, b1, b2, eps, wd = hyper
+        for prm, m1, m2, gr in ((self.U, self.mU, self.vU, dU), (self.V, self.mV, self.vV, dV)):
+            if prm.size:
+                self.orc.adam(prm, m1, m2, gr, step, lr=lr, betas=(b1, b2), eps=eps, wd=wd)
+        terms[:Bk] = torch.from_numpy(term)
+
+
+def _shard_worker(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mfcd import dist as mdist
+        from mfcd.batching import pack_records
+        rng = np.random.default_rng(8)
+        n, m, d, B, N = 41, 30, 8, 16, 16 * 9 + 5
+        U0 = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+        V0 = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+        u, i = rng.integers(0, n, N), rng.integers(0, m, N)
+        j = (i + 1 + rng.integers(0, m - 1, N)) % m
+        z = rng.integers(0, 2, N).astype(np.float64)
+        stream = torch.from_numpy(pack_records(np.stack([u, i, j, z], 1), n, m))
+        comp = OracleShardCompute(U0, V0, rank, world, 1e-3, 1e-5)
+        losses = mdist.train_steps_sharded(comp, stream, B, 0, (1e-3, 0.9, 0.999, 1e-8, 1e-5))
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), U=comp.U, V=comp.V, vV=comp.vV, losses=losses.numpy(),
+                 bounds=np.array([comp.u_lo, comp.u_hi, comp.v_lo, comp.v_hi]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_row_sharded_run_equals_single_process_same_batch(tmp_path, orc):
+    """World 2 over gloo: each rank holds half the rows of U, V, m, v; the batch stays B (NOT B*world); one int32
+    all-reduce of the batch's rows per step.  The concatenated shards must equal the single-process oracle run with
+    the SAME batch size, and both ranks must report the same step losses."""
+    from oracle import oracle as O
+    world = 2
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (dict(np.load(tmp_path / f"s{r}.npz")) for r in range(world))
+    np.testing.assert_array_equal(r0["losses"], r1["losses"])
+    assert r0["bounds"].tolist() == [0, 20, 0, 15] and r1["bounds"].tolist() == [20, 41, 15, 30]
+    rng = np.random.default_rng(8)
+    n, m, d, B, N = 41, 30, 8, 16, 16 * 9 + 5
+    U0 = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    V0 = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+    u, i = rng.integers(0, n, N), rng.integers(0, m, N)
+    j = (i + 1 + rng.integers(0, m - 1, N)) % m
+    z = rng.integers(0, 2, N).astype(np.float64)
+    ref = O.new_state(U0, V0)
+    ref_loss = orc.train_steps(ref, u, i, j, z, B, 0, lr=1e-3, wd=1e-5)
+    np.testing.assert_allclose(r0["losses"], ref_loss, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(np.concatenate([r0["U"], r1["U"]]), ref["U"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(np.concatenate([r0["V"], r1["V"]]), ref["V"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(np.concatenate([r0["vV"], r1["vV"]]), ref["vV"], rtol=1e-5, atol=1e-12)
+
+
+def test_bench_starts_its_own_ranks_and_relays_one_json_line():
+    """`python bench.py --gpus 2` outside torch.distributed.run must spawn the ranks itself, print exactly one JSON
+    line (rank 0's) on stdout and exit 0; a failing child must give a non-zero exit.  Uses the
+    launcher self-test mode (gloo rendezvous on CPU), so no GPU is touched."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    ok = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dp-mode", "selftest"],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [ln for ln in ok.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["sum_of_ranks_plus_one"] == 3.0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dp-mode", "selftest",
+                          "--workload", "no-such-workload"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert bad.returncode != 0
