@@ -160,10 +160,11 @@ class Runner:
     def reset_events(self):
         self.train_events = []
 
-    def run(self, steps, record=False):
+    def run(self, steps, record=False, bind=None):
         """Enqueue `steps` optimiser steps (+ a validation pass after every completed epoch). No host sync.
-        Returns the number of training samples consumed."""
+        Returns the number of training samples consumed.  `bind`: step a scratch model instead (clock_ramp)."""
         B, consumed = self.cfg["B"], 0
+        bind = bind or self.bind
         while steps > 0:
             if self.stream is None:
                 if self.pre.pending is None:
@@ -175,7 +176,7 @@ class Runner:
             if record:
                 e0, e1 = self._event(), self._event()
                 e0.record()
-            self.engine.train_steps(self.bind, self.stream[lo:hi], B)
+            self.engine.train_steps(bind, self.stream[lo:hi], B)
             if record:
                 e1.record()
                 self.train_events.append((e0, e1, take))
@@ -288,15 +289,21 @@ def clock_ramp(runner, seconds):
     scratch = copy.deepcopy(runner.model)
     opt = torch.optim.Adam(scratch.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
     bind = engine.AdamBinding(scratch, opt)
-    B = cfg["B"]
-    chunk = runner.train.dev[: 20 * B]
+    saved = (runner.stream, runner.pos, runner.pre.pending, runner.gen.get_state())
+    if runner.stream is None:       # the ramp walks the same code path as the timed region: Runner.run, events included
+        runner.stream, runner.pos = runner.train.dev, 0
     t0 = time.perf_counter()
     calls = 0
     while time.perf_counter() - t0 < seconds:
         for _ in range(16):
-            engine.train_steps(bind, chunk, B)
+            runner.pos = 0
+            runner.run(20, record=True, bind=bind)
         calls += 16
         torch.cuda.synchronize()
+        runner.event_pool.extend(e for a, b, _ in runner.train_events for e in (a, b))
+        runner.reset_events()
+    runner.stream, runner.pos, runner.pre.pending = saved[0], saved[1], saved[2]
+    runner.gen.set_state(saved[3])
     return {"untimed": True, "seconds": round(time.perf_counter() - t0, 3), "calls": calls,
             "what": "20-step fused calls on a scratch copy of the model, before the warm-up steps"}
 

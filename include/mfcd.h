@@ -175,7 +175,9 @@ int mfcd_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float 
  * bf16 factor storage (BASELINE.json configs[2]; the reference has no such mode, the rounding points are defined
  * here and in oracle/mfcd_oracle.c): U [n][d], V [m][d] are bf16 in HBM; each step reads them as such, does all
  * arithmetic and keeps the Adam moments in fp32, and rounds the updated parameters to the nearest bf16 (ties to
- * even) once, when they are written back.  Always the streaming form; 20 bytes per element per step instead of 24.
+ * even) once, when they are written back.  Streaming form (20 bytes per element per step instead of 24) or, where
+ * it applies, the resident form (fast Adam flavour): the register copy is rounded after every update, the same
+ * rounding point, so both forms agree with the oracle's definition.
  */
 int mfcd_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, float *mV, float *vV,
                           const mfcd_sample *samples, int64_t N, int B, int64_t step0, int n, int m,
@@ -229,6 +231,15 @@ int mfcd_apply_step(float *U, float *V, float *mU, float *vU, float *mV, float *
 int mfcd_dense_grad(const float *U, const float *V, const mfcd_sample *samples, int B, int n, int m,
                     int d, int batch_divisor, float *gradU, float *gradV, float *term_out,
                     void *stream);
+/*
+ * Backward of the model's forward for ANY loss on its output (autograd support of MatrixFactorization.forward,
+ * structure.py:773-795): g[t] = dLoss/dx_t for B samples (x_t = the pre-sigmoid score); overwrites gradU [n][d],
+ * gradV [m][d] with  dU[u]+=g(V[i]-V[j]), dV[i]+=g U[u], dV[j]-=g U[u]  accumulated in batch order (what
+ * autograd's index_put_(accumulate=True) builds); rows no sample touches are 0.
+ */
+int mfcd_dense_grad_from_coefficients(const float *U, const float *V, const mfcd_sample *samples,
+                                      const float *g, int B, int n, int m, int d, float *gradU,
+                                      float *gradV, void *stream);
 int mfcd_adam_dense(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
                     const float *gradU, const float *gradV, int64_t step, int n, int m, int d,
                     double lr, double beta1, double beta2, double eps, double weight_decay,
@@ -311,7 +322,8 @@ int mfcd_uvt_stats(const float *U, const float *V, const float *X, int n, int m,
 
 /*
  * k rows of UV^T: out[r][c] = sum_k U[row_ids[r]][k] * V[c][k]   (structure.py:389-392 computes
- * the full product to read two rows).
+ * the full product to read two rows).  row_ids is a device array; a row id outside [0, n) yields a row of NaN
+ * (the Python host validates the ids and raises IndexError, as U[row] would).
  */
 int mfcd_uvt_rows(const float *U, const float *V, const int32_t *row_ids, int k, int n, int m,
                   int d, float *out, void *stream);

@@ -34,7 +34,7 @@
 // a width that was not built is simply absent (weak symbol) and the streaming form is used for it.
 #define MFCD_DECL(d)                                                                                                  \
     extern "C" int mfcd_resident_launch_d##d(const mfcd_detail::ResidentArgs *, int, int, void *) __attribute__((weak)); \
-    extern "C" int mfcd_resident_occupancy_d##d(int, int, int, int) __attribute__((weak));
+    extern "C" int mfcd_resident_occupancy_d##d(int, int, int, int, int) __attribute__((weak));
 MFCD_DECL(2) MFCD_DECL(4) MFCD_DECL(8) MFCD_DECL(16) MFCD_DECL(32) MFCD_DECL(64) MFCD_DECL(128) MFCD_DECL(256)
 #undef MFCD_DECL
 
@@ -44,7 +44,7 @@ int g_resident_math = 1;   // mfcd_set_resident_math: 1 = fast flavour (default)
 Tuning g_tune;             // mfcd_set_tuning
 
 typedef int (*ResidentLauncher)(const ResidentArgs *, int, int, void *);
-typedef int (*ResidentOccupancy)(int, int, int, int);
+typedef int (*ResidentOccupancy)(int, int, int, int, int);
 
 static ResidentLauncher launcher_for(int d)
 {
@@ -91,16 +91,16 @@ int resident_lookahead(int64_t N, int B, int n, int m)
 // Workgroups of the instantiation (d, Q, look, fast) one CU holds at once, as the runtime reports it for the actual
 // code object (register and LDS use), capped by the hardware's own admission rule for 256-thread workgroups
 // (MI355X_MICROARCH.md, Residency: min(API, 8, ...)); cached per instantiation.  0 = unknown (no device / query failed).
-static int resident_blocks_per_cu(int d, int Q, int look, int fast, int lds_pad)
+static int resident_blocks_per_cu(int d, int Q, int look, int fast, int bf16, int lds_pad)
 {
     static std::mutex mu;
     static std::vector<std::pair<long long, int>> cache;
-    const long long key = ((((long long)d * 64 + Q) * 16 + look) * 2 + fast) * 262144 + lds_pad;
+    const long long key = (((((long long)d * 64 + Q) * 16 + look) * 2 + fast) * 2 + bf16) * 262144 + lds_pad;
     std::lock_guard<std::mutex> lock(mu);
     for (auto &e : cache)
         if (e.first == key) return e.second;
     int occ = 0;
-    if (ResidentOccupancy fn = occupancy_for(d)) occ = fn(Q, look, fast, lds_pad);
+    if (ResidentOccupancy fn = occupancy_for(d)) occ = fn(Q, look, fast, bf16, lds_pad);
     if (occ > 8) occ = 8;
     if (occ < 0) occ = 0;
     cache.emplace_back(key, occ);
@@ -112,7 +112,7 @@ static int resident_blocks_per_cu(int d, int Q, int look, int fast, int lds_pad)
 // is 16 for Q <= 2 (4 workgroups of 4 waves hide each other's hand-off latency: +7 % at C2 over 2 per CU) and 8 above;
 // whether the code object really admits that many is asked of the runtime (resident_blocks_per_cu) and the plan is
 // refused otherwise, so that a compiler that allocates more registers ends in the streaming form, not in a spin.
-ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus)
+ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, bool bf16)
 {
     ResidentPlan pl{};
     pl.ok = false;
@@ -120,15 +120,17 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus)
     const int64_t T = (int64_t)(n + m) * d;
     const int forced_q = g_tune.resident_q;
     const int wpc = g_tune.resident_wpc > 0 ? g_tune.resident_wpc : 16;
-    const int look = resident_lookahead(N, B, n, m);
-    static const int kQ[4] = {1, 2, 4, 16};
-    for (int qi = 0; qi < 4; ++qi) {
+    int look = resident_lookahead(N, B, n, m);
+    const bool fast = bf16 ? true : g_resident_math != 0;   // bf16 tables: fast flavour only
+    if (bf16 && look >= 8) look = 4;
+    static const int kQ[5] = {1, 2, 4, 16, 32};
+    for (int qi = 0; qi < 5; ++qi) {
         const int Q = kQ[qi];
         if ((64 * Q) % d != 0 || (forced_q && Q != forced_q)) continue;
         const int64_t nw = (T + 64 * (int64_t)Q - 1) / (64 * Q);
         const int want_wpc = Q <= 2 ? wpc : 8;
         if (nw <= (int64_t)num_cus * want_wpc && nw <= kResidentMaxWaves) {
-            const int occ = resident_blocks_per_cu(d, Q, look, g_resident_math != 0, g_tune.lds_pad);
+            const int occ = resident_blocks_per_cu(d, Q, look, fast, bf16, g_tune.lds_pad);
             const int blocks = (int)((nw + 3) / 4);
             if (occ > 0 && (int64_t)blocks > (int64_t)occ * num_cus) continue;   // would not be resident: next Q or none
             pl.ok = true;
@@ -136,7 +138,8 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus)
             pl.NW = (int)nw;
             pl.blocks = blocks;
             pl.lookahead = look;
-            pl.fast_math = g_resident_math != 0;
+            pl.fast_math = fast;
+            pl.bf16 = bf16;
             return pl;
         }
     }
@@ -232,6 +235,7 @@ int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev, const mf
     a.lookahead = pl.lookahead;
     a.tag_base = tag_base;
     a.fast_math = pl.fast_math;
+    a.bf16 = pl.bf16;
     a.lds_pad = g_tune.lds_pad;
     ResidentLauncher fn = launcher_for(d);
     if (!fn) return MFCD_EINVAL;

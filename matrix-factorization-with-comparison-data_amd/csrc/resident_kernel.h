@@ -97,6 +97,7 @@ struct ResidentArgs {
     int B, n, m, K, NW;
     int lookahead;           // 0: publish right before use (any B); >0: look-ahead form (B <= 64)
     int fast_math;           // Adam arithmetic flavour: 0 IEEE-rounded, 1 v_sqrt / Newton-corrected rcp
+    int bf16;                // factor tables are bf16 in HBM (cold->U / V then point to 2-byte elements)
     int lds_pad;             // unused dynamic LDS per workgroup: caps workgroups per CU so placement is even
     AdamStatic ac;
 };
@@ -124,13 +125,22 @@ struct Masks {
 //   before k) from a rolled-forward register copy.  The memory-side hand-off then overlaps W-1 steps of work
 //   instead of sitting on every step's critical chain.  Same arithmetic in the same order -> identical bits.
 // FAST: Adam arithmetic flavour (train_common.h): false = IEEE-rounded div/sqrt, true = v_sqrt / Newton-corrected rcp.
-template <int D, int Q, int LOOK, bool FAST>
-__global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
+// BF16: the factor tables are bf16 in HBM (BASELINE configs[2]); the slice lives in registers as fp32 values that are
+//   bf16-representable: every Adam update is followed by ONE round-to-nearest-even, the rounding point the streaming
+//   bf16 form and the oracle define (mfcd_train_steps_bf16), so published rows are exactly what a step would re-read.
+// Slices of Q >= 16 registers per array (C3: Q = 32, 2048 waves at two per SIMD) keep their row-gradient accumulators in
+//   LDS instead of Q more registers: they are touched only in a hit step (the common step runs Adam with g = 0 and
+//   never reads them), and a hit adds to the S registers of its row by address instead of a Q-long predicated chain.
+template <int D, int Q, int LOOK, bool FAST, bool BF16 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Q >= 16 ? 2 : 1)))
+void resident_train_kernel(ResidentArgs a)
 {
     constexpr int S = D >= 64 ? D / 64 : 1;    // registers per row (gathered layout: lane <-> column lane + 64*s)
     constexpr int RPR = D < 64 ? 64 / D : 1;   // rows per register when D < 64
     constexpr int EW = 64 * Q;
     static_assert(EW % D == 0, "a wave's slice must hold whole rows");
+    constexpr bool GRL = Q >= 16;             // row-gradient accumulators in LDS
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];   // [4 waves][64*Q] when GRL (+ the lds_pad knob)
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (gw >= a.NW) return;  // whole wave
@@ -146,17 +156,23 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
     auto elem_offset = [&](int64_t e) { return (int64_t)make_row_map(a.n, a.m).table_row((int)(e / D)) * D + (e % D); };
 
     // ---- load my slice of the state into registers ----
-    float p[Q], m1[Q], m2[Q], gr[Q];
+    float p[Q], m1[Q], m2[Q], gr[GRL ? 1 : Q];
+    float *const lgr = lds_dyn + (threadIdx.x >> 6) * (GRL ? EW : 0);   // this wave's accumulators: element q*64 + lane
+    auto post = [](float x) {   // the rounding point of bf16 factor storage: once per update
+        if constexpr (BF16) return (float)(mfcd_bf16)x;
+        else return x;
+    };
     {
         const ResidentCold c = *a.cold;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int64_t e = ebase + q * 64 + lane;
             p[q] = m1[q] = m2[q] = 0.0f;
+            if constexpr (GRL) lgr[q * 64 + lane] = 0.0f;
             if (e < T) {
                 const int64_t o = elem_offset(e);
-                if (!elem_is_item(e)) { p[q] = c.U[o]; m1[q] = c.mU[o]; m2[q] = c.vU[o]; }
-                else { p[q] = c.V[o]; m1[q] = c.mV[o]; m2[q] = c.vV[o]; }
+                if (!elem_is_item(e)) { p[q] = BF16 ? (float)((const mfcd_bf16 *)c.U)[o] : c.U[o]; m1[q] = c.mU[o]; m2[q] = c.vU[o]; }
+                else { p[q] = BF16 ? (float)((const mfcd_bf16 *)c.V)[o] : c.V[o]; m1[q] = c.mV[o]; m2[q] = c.vV[o]; }
             }
         }
     }
@@ -296,16 +312,60 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             du[0] = __shfl(du[0], lcol, MFCD_WAVE);
             dv[0] = __shfl(dv[0], lcol, MFCD_WAVE);
         }
+        if constexpr (GRL) {
+            // by address: the S accumulators of each owned row (role order u, i, j = the register form's order per element)
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int rowq = Rlo + (q * 64 + lane) / D;
-            const int sq = D >= 64 ? (q * 64 % D) / 64 : 0;
-            if (own[0] && rowq == rows[0]) gr[q] += du[sq];
-            if (own[1] && rowq == rows[1]) gr[q] += dv[sq];
-            if (own[2] && rowq == rows[2]) gr[q] += -dv[sq];
+            for (int r = 0; r < 3; ++r) {
+                if (!own[r]) continue;
+                const int q0 = reg_of(rows[r]);
+                if constexpr (D >= 64) {
+#pragma unroll
+                    for (int s2 = 0; s2 < S; ++s2)
+                        lgr[(q0 + s2) * 64 + lane] += r == 0 ? du[s2] : (r == 1 ? dv[s2] : -dv[s2]);
+                } else {
+                    if (lane / D == (rows[r] - Rlo) % RPR) lgr[q0 * 64 + lane] += r == 0 ? du[0] : (r == 1 ? dv[0] : -dv[0]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int rowq = Rlo + (q * 64 + lane) / D;
+                const int sq = D >= 64 ? (q * 64 % D) / 64 : 0;
+                if (own[0] && rowq == rows[0]) gr[q] += du[sq];
+                if (own[1] && rowq == rows[1]) gr[q] += dv[sq];
+                if (own[2] && rowq == rows[2]) gr[q] += -dv[sq];
+            }
         }
         DBG_ADD(2, STAMP() - t_poll1);
         return true;
+    };
+
+    // dense Adam over the slice for one step; `hit`: this wave accumulated row gradients in this step (wave-uniform)
+    auto step_update = [&](bool hit, const StepScalars &sc) {
+        if constexpr (GRL) {
+            if (hit) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float g = lgr[q * 64 + lane];
+                    lgr[q * 64 + lane] = 0.0f;
+                    adam_update_t<FAST>(p[q], m1[q], m2[q], g, a.ac, sc);
+                    p[q] = post(p[q]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    adam_update_t<FAST>(p[q], m1[q], m2[q], 0.0f, a.ac, sc);
+                    p[q] = post(p[q]);
+                }
+            }
+        } else {
+            // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
+            adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc);
+            if constexpr (BF16) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) p[q] = post(p[q]);
+            }
+        }
     };
 
     if constexpr (LOOK > 0) {
@@ -427,13 +487,18 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                         }
                         if (phase == 1) {                                  // step j itself: dense-only for this row
 #pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, sc_j);
+                            for (int s2 = 0; s2 < S; ++s2) {
+                                adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, sc_j);
+                                pp[s2] = post(pp[s2]);
+                            }
                         }
 #pragma unroll
                         for (int b2 = 1; b2 < kk; ++b2) {
 #pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2)
+                            for (int s2 = 0; s2 < S; ++s2) {
                                 adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b2]);
+                                pp[s2] = post(pp[s2]);
+                            }
                         }
                         const u64 mr[3] = {(u64)__ballot(rk.u == R), (u64)__ballot(rk.i == R), (u64)__ballot(rk.j == R)};
                         const unsigned tag = a.tag_base + (unsigned)k + 1u;
@@ -516,8 +581,10 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #pragma unroll
                         for (int b2 = 1; b2 < kk; ++b2) {
 #pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2)
+                            for (int s2 = 0; s2 < S; ++s2) {
                                 adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b2]);
+                                pp[s2] = post(pp[s2]);
+                            }
                         }
                         u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + r) * D;
                         const unsigned tag = a.tag_base + (unsigned)k + 1u;
@@ -562,8 +629,10 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             for (int r = 1; r < NWIN; ++r) win |= winR[r];
             const StepScalars sc_next = *sc_ptr++;
 
+            if constexpr (!GRL) {
 #pragma unroll
-            for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
+                for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
+            }
             if constexpr (ROWWIN) publish_phase(k, false, 1, sc_cur);
             // a wave with a hit or a fresh publish is on somebody's critical chain, the waves on the common path have
             // slack: it issues ahead of them until its step is done
@@ -591,14 +660,12 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
 #endif
             }
 #if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-            // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
-            adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc_cur);
+            step_update(urgent, sc_cur);
             publish_phase(k, false, ROWWIN ? 2 : 0, sc_cur);
             if (urgent) __builtin_amdgcn_s_setprio(0);
 #else
             [[maybe_unused]] const u64 t_adam0 = STAMP();
-            // scalar, not packed pairs: measured 15 % slower here with v_pk_* (0.94 -> 1.15 us/step at C2)
-            adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc_cur);
+            step_update(urgent, sc_cur);
             [[maybe_unused]] const u64 t_adam1 = STAMP();
             DBG_ADD(3, t_adam1 - t_adam0);
             publish_phase(k, false, ROWWIN ? 2 : 0, sc_cur);
@@ -643,12 +710,16 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
             const int Bk = batch_size(k);
             const float inv_batch = 1.0f / (float)Bk;
             const StepScalars sc = a.sc[k];
+            if constexpr (!GRL) {
 #pragma unroll
-            for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
+                for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
+            }
+            bool any_hit = false;
             for (int base = 0; base < Bk; base += MFCD_WAVE) {
                 const mfcd_sample s = load_record(a.samples, pos0, Bk, base, lane);
                 const Masks M = scan(s, Bk, base);
                 u64 mask = M.mu | M.mi | M.mj;
+                any_hit = any_hit || mask != 0ull;
                 while (mask) {
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -661,7 +732,7 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
                     if (__builtin_amdgcn_readfirstlane((int)!ok)) return;
                 }
             }
-            adam_update_q<FAST, Q, false>(p, m1, m2, gr, a.ac, sc);
+            step_update(any_hit, sc);
             if (k + 1 < a.K) publish(k + 1);
         }
     }
@@ -684,8 +755,15 @@ __global__ __launch_bounds__(256) void resident_train_kernel(ResidentArgs a)
         const int64_t e = ebase + q * 64 + lane;
         if (e < T) {
             const int64_t o = elem_offset(e);
-            if (!elem_is_item(e)) { c.U[o] = p[q]; c.mU[o] = m1[q]; c.vU[o] = m2[q]; }
-            else { c.V[o] = p[q]; c.mV[o] = m1[q]; c.vV[o] = m2[q]; }
+            if (!elem_is_item(e)) {
+                if constexpr (BF16) ((mfcd_bf16 *)c.U)[o] = (mfcd_bf16)p[q];   // exact: p is bf16-representable
+                else c.U[o] = p[q];
+                c.mU[o] = m1[q]; c.vU[o] = m2[q];
+            } else {
+                if constexpr (BF16) ((mfcd_bf16 *)c.V)[o] = (mfcd_bf16)p[q];
+                else c.V[o] = p[q];
+                c.mV[o] = m1[q]; c.vV[o] = m2[q];
+            }
         }
     }
 }

@@ -469,7 +469,7 @@ bool resident_feasible(int n, int m, int d, int cus)
 {
     if (d < 2 || d > 256 || (d & (d - 1)) != 0) return false;
     const int64_t T = (int64_t)(n + m) * d;
-    static const int kQ[4] = {1, 2, 4, 16};
+    static const int kQ[5] = {1, 2, 4, 16, 32};
     for (int Q : kQ) {
         if ((64 * Q) % d != 0) continue;
         const int64_t nw = (T + 64 * (int64_t)Q - 1) / (64 * Q);
@@ -717,9 +717,9 @@ FormChoice choose_form(bool f32, bool resident_planned, int64_t N, int B, int n,
         return c;
     }
     bool resident_ok = false;
-    if (f32 && resident_planned && g_train_path != 1 && N > 0 && nsteps <= 0x7fffffff &&
+    if (resident_planned && g_train_path != 1 && N > 0 && nsteps <= 0x7fffffff &&
         nsteps + 1 < ((int64_t)1 << kTagStepBits)) {
-        c.rp = mfcd_detail::plan_resident(N, B, n, m, d, device_cus());
+        c.rp = mfcd_detail::plan_resident(N, B, n, m, d, device_cus(), !f32);
         resident_ok = c.rp.ok;
     }
     if (g_train_path == 2) {
@@ -754,11 +754,11 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     char *base = (char *)workspace;
     int *status = (int *)workspace;
 
-    constexpr bool kF32 = sizeof(TP) == 4;   // the resident / local forms hold fp32 state; bf16 factors stream
+    constexpr bool kF32 = sizeof(TP) == 4;   // bf16 factor tables: streaming or resident form (the local form is fp32 only)
     const FormChoice fc = choose_form(kF32, L.resident, N, B, n, m, d);
     if (fc.form < 0) return fc.form;
 
-    if constexpr (kF32) if (fc.form == 2 || fc.form == 3) {
+    if (fc.form == 2 || fc.form == 3) {
         // ---- persistent forms: ONE launch for all nsteps (resident.hip / local.hip) behind ONE prologue kernel ----
         const bool resident = fc.form == 2;
         StepScalars *sc_dev = (StepScalars *)(base + L.stage_off + kColdBytes);
@@ -993,6 +993,22 @@ extern "C" int mfcd_dense_grad(const float *U, const float *V, const mfcd_sample
     return 0;
 }
 
+extern "C" int mfcd_dense_grad_from_coefficients(const float *U, const float *V, const mfcd_sample *samples,
+                                                 const float *g, int B, int n, int m, int d, float *gradU,
+                                                 float *gradV, void *stream)
+{
+    if (int rc = check_common(U, V, n, m, d)) return rc;
+    if (!gradU || !gradV || B < 0) return MFCD_EINVAL;
+    if (B > 0 && (!samples || !g)) return MFCD_EINVAL;
+    const void *ptrs[] = {U, V, gradU, gradV};
+    const Plan pl = make_plan(ptrs, 4, n, m, d);
+    AdamConst ac{};
+    dispatch_step<1, float>(pl, (hipStream_t)stream, U, V, (float *)nullptr, (float *)nullptr, nullptr, nullptr, nullptr,
+                            nullptr, samples, g, B, 0.0f, n, m, d, ac, nullptr, gradU, gradV);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mfcd_adam_dense(float *U, float *V, float *mU, float *vU, float *mV, float *vV, const float *gradU,
                                const float *gradV, int64_t step, int n, int m, int d, double lr, double beta1,
                                double beta2, double eps, double weight_decay, void *stream)
@@ -1155,6 +1171,21 @@ void shard_range(int rows, int rank, int world, int *lo, int *hi)
 
 size_t shard_xbuf_bytes(int B, int d) { return align256(sizeof(float) * 3 * (size_t)B * d); }
 
+// BCE terms of a batch from the exchange buffer alone: what workgroup 0 of the MODE 3 step records, for a rank whose
+// shard is EMPTY (more ranks than rows) and therefore launches no step kernel.  Same dot-product order.
+__global__ __launch_bounds__(256) void shard_terms_kernel(const float *__restrict__ xb, const mfcd_sample *__restrict__ batch,
+                                                          int Bk, int Bcap, int d, float *__restrict__ loss_terms)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= Bk) return;
+    const float *ur = xb + (int64_t)t * d, *vi = xb + ((int64_t)Bcap + t) * d, *vj = xb + ((int64_t)2 * Bcap + t) * d;
+    float acc = 0.0f;
+    for (int k = lane; k < d; k += MFCD_WAVE) acc += ur[k] * (vi[k] - vj[k]);
+    const float p = sigmoid_f32(wave_sum64(acc));
+    if (lane == 0) loss_terms[t] = bce_term_f32(p, batch[t].z);
+}
+
 }  // namespace
 
 extern "C" int mfcd_shard_rows(int rows, int rank, int world, int *lo, int *hi)
@@ -1189,7 +1220,15 @@ extern "C" int mfcd_shard_apply(float *U_shard, float *V_shard, float *mU, float
 {
     if (!batch || !xbuf || Bk <= 0 || B <= 0 || Bk > B || d <= 0 || d > MFCD_MAX_D || step < 1) return MFCD_EINVAL;
     const int nu = u_hi - u_lo, nv = v_hi - v_lo;
-    if (nu < 0 || nv < 0 || nu + nv <= 0) return MFCD_EINVAL;
+    if (nu < 0 || nv < 0) return MFCD_EINVAL;
+    if (nu + nv == 0) {   // this rank owns no row (world > rows): nothing to update, only the step's loss terms
+        if (loss_terms) {
+            hipLaunchKernelGGL(shard_terms_kernel, dim3((Bk + 3) / 4), dim3(256), 0, (hipStream_t)stream, xbuf, batch, Bk,
+                               B, d, loss_terms);
+            MFCD_HIP_TRY(hipGetLastError());
+        }
+        return 0;
+    }
     if ((nu > 0 && (!U_shard || !mU || !vU)) || (nv > 0 && (!V_shard || !mV || !vV))) return MFCD_EINVAL;
     const void *ptrs[] = {U_shard, V_shard, mU, vU, mV, vV, xbuf};
     // an empty table side is legal (a rank may own rows of one table only when world > rows): one dummy row count

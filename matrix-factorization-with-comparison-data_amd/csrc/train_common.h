@@ -143,6 +143,7 @@ struct ResidentPlan {
     int Q, NW, blocks;
     int lookahead;   // 0, 4 or 8: the instantiation the launch uses
     bool fast_math;
+    bool bf16;       // bf16 factor tables
 };
 
 constexpr unsigned kSpinLimitDefault = 1u << 22;  // polls before a wave gives up (~seconds); sets status = 1
@@ -163,7 +164,7 @@ extern int g_resident_math;
 
 int set_uvt_wpe128(int v);   // uvt.hip
 
-ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus);
+ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, bool bf16 = false);
 int resident_lookahead(int64_t N, int B, int n, int m);
 
 // One kernel in front of a resident / local launch: pinned staging slot -> workspace, and (xs != nullptr) the

@@ -90,19 +90,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restrict__ part, int n, int m, int d,
                                                            float *__restrict__ bar)
 {
-    const int tab = blockIdx.y;
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < d; k += gridDim.x * 256) {
-        const int rows = tab ? m : n, nsl = slices_for(rows);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int sl = 0;
-        for (; sl + 3 < nsl; sl += 4) {
-            a0 += part[((size_t)tab * kSlices + sl) * d + k];
-            a1 += part[((size_t)tab * kSlices + sl + 1) * d + k];
-            a2 += part[((size_t)tab * kSlices + sl + 2) * d + k];
-            a3 += part[((size_t)tab * kSlices + sl + 3) * d + k];
-        }
-        for (; sl < nsl; ++sl) a0 += part[((size_t)tab * kSlices + sl) * d + k];
-        bar[(size_t)tab * d + k] = (float)(((a0 + a1) + (a2 + a3)) / (double)rows);
+    // 64 columns per workgroup, four threads per column: thread q sums the slices q, q+4, ... (plus the tail on q = 0),
+    // then (a0 + a1) + (a2 + a3): the order centre_vectors_kernel uses when it does this itself
+    __shared__ double red[4][64];
+    const int tab = blockIdx.y, q = threadIdx.x >> 6, k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rows = tab ? m : n, nsl = slices_for(rows), full = nsl & ~3;
+    double a = 0.0;
+    if (k < d) {
+        for (int sl = q; sl < full; sl += 4) a += part[((size_t)tab * kSlices + sl) * d + k];
+        if (q == 0)
+            for (int sl = full; sl < nsl; ++sl) a += part[((size_t)tab * kSlices + sl) * d + k];
+    }
+    red[q][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (q == 0 && k < d) {
+        const int c = threadIdx.x & 63;
+        bar[(size_t)tab * d + k] = (float)(((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) / (double)rows);
     }
 }
 
@@ -467,7 +470,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
 #pragma unroll
     for (int k = 0; k < D / 2; ++k) asm volatile("" : "+v"(u[k]));
     asm volatile("" : "+v"(rmv), "+v"(x0v));
-    const float *xlane = X + (int64_t)myrow * m + 4 * half;   // + cb + 8g: this lane's 16-byte pieces of a tile
+    const float *xrow0 = X + (int64_t)myrow * m;   // + cb + 8g + 4*half: this lane's 16-byte pieces of a tile
     // fragment address of tile j of a stage: row 32j + l31, chunks half*CPR/2 + q (one piece, consecutive)
     const int f0 = l31 * CPR + half * (CPR / 2);
     const unsigned frag0 = (unsigned)(((f0 >> 6) * PF + (f0 & 63) * 4) * 4);          // bytes, tile 0
@@ -486,39 +489,39 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     // i.e. longer than the 64-MFMA chain of a d = 128 tile, so the epilogue used to stall on them (C3 58 % vs C5 81 %
     // in-kernel).  The two register sets swap roles every tile (no copy: copying a pending load would wait for it).
     auto load_x = [&](int cb, f32x4 (&xq)[4]) {
-        if (XV && cb + 32 <= c_end) {
-            const f32x4 *xp = reinterpret_cast<const f32x4 *>(xlane + cb);
+        // branch-free (a branch here makes the values phi nodes, which the compiler resolves with register copies of
+        // loads still in flight, i.e. with a wait): 16-byte pieces clamped to stay inside the row; columns at or past
+        // the split's end are masked in the epilogue
+        // With PFX the loads are inline asm: the values stay in flight ACROSS the loop's back edge, where the compiler's
+        // wait insertion gives up counting and drains everything (vmcnt(0)) at the first use; issued from asm it does
+        // not track them at all, and the counted waits below (wait_x) are the only ones.
+        if constexpr (XV) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const float *src = xrow0 + min(cb + 8 * g + 4 * half, m - 4);
 #if MFCD_UVT_EXP == 1
                 xq[g] = f32x4{(float)cb, 1.f, 2.f, 3.f};
 #else
-                xq[g] = xp[2 * g];
+                if constexpr (PFX) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xq[g]) : "v"(src) : "memory");
+                else xq[g] = *reinterpret_cast<const f32x4 *>(src);
 #endif
             }
         } else {
-            const float *xrow = xlane - 4 * half;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xq[r >> 2][r & 3] = xrow[min(cb + tile_row(r, half), m - 1)];
+            for (int r = 0; r < 16; ++r) xq[r >> 2][r & 3] = xrow0[min(cb + tile_row(r, half), m - 1)];
         }
     };
+    static_assert(!PFX || XV, "the prefetch form issues its X loads as 16-byte inline-asm loads");
+    constexpr int kPend = 4;   // vector-memory operations one X prefetch puts in flight
     f32x4 xa[4], xb[4];
-    int tile_no = 0, pend = 0;
     if (PFX && active) load_x(c_begin, xa);
 
-    auto tile = [&](int cb, int ncb, int j, const float *cms, f32x4 (&xq)[4], f32x4 (&xn)[4]) __attribute__((always_inline)) {
+    auto tile = [&](int cb, int ncb, int j, const float *cms, f32x4 (&xq)[4], f32x4 (&xn)[4], bool deep) __attribute__((always_inline)) {
                 const bool full = cb + 32 <= c_end;   // wave-uniform
                 MFCD_STAMP(tt0);
                 asm volatile("" ::: "memory");   // the stage's LDS-DMA (issued above) stays OLDER than this prefetch
-                pend = 0;
-                if constexpr (PFX) {
-                    if (ncb >= 0) {
-                        load_x(ncb, xn);
-                        pend = (XV && ncb + 32 <= c_end) ? 4 : 16;   // vector-memory operations the prefetch put in flight
-                    }
-                } else {
-                    load_x(cb, xq);          // this tile's own values, 16 loads in flight under its MFMA chain
-                }
+                if constexpr (PFX) load_x(ncb, xn);   // the NEXT tile's values (a dummy re-read of this tile at the very end)
+                else load_x(cb, xq);                 // this tile's own values, in flight under its MFMA chain
                 asm volatile("" ::: "memory");
                 f32x16 acc;
 #pragma unroll
@@ -572,7 +575,18 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                 // x - xm, s*x up into the MFMA chain and with them the wait for the X loads (and, as an LDS-DMA is in
                 // flight, for everything: vmcnt(0)) to the top of the chain
                 // (tied to the accumulator so that it stays behind the last MFMA)
-                asm volatile("" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]));
+                if constexpr (PFX) {
+                    // this tile's X values were requested one tile ago; younger than them (and allowed to stay in
+                    // flight) are the next tile's request and, for the first tile of a stage, the next stage's DMA pieces
+                    if (deep)
+                        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3])
+                                     : "n"(PPW + kPend) : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3])
+                                     : "n"(kPend) : "memory");
+                } else {
+                    asm volatile("" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]));
+                }
                 lds_wait4<0>(cq[0], cq[1], cq[2], cq[3]);
                 // acc[4g+e] = (U V^T)[myrow][cb + 8g + 4*half + e]; cq[g][e] = the matching column mean
                 float pac, paa, pe, psa, psc, pscc;
@@ -651,26 +665,34 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
         cyc_dma += td1 - td0;
 #endif
         if (active) {
+            if constexpr (PFX) {
+                // tiles in PAIRS, straight-line: the first uses xa and requests the second's values into xb, the second
+                // uses xb and requests the next pair's (or the next stage's first tile's) into xa — fixed roles, no copy
+                static_assert((TC / 32) % 2 == 0, "the X prefetch ping-pong needs an even number of tiles per stage");
 #pragma unroll 1
-            for (int j = 0; j < TC / 32; ++j) {
-                const int cb = c0 + 32 * j;
-                if (cb >= c_end) continue;
-                // the tile after this one (same stage, or the first of the next stage; -1: none)
-                const int ncb = (j + 1 < TC / 32 && cb + 32 < c_end) ? cb + 32 : (c0 + TC < c_end ? c0 + TC : -1);
-                if constexpr (PFX) {
-                    if ((tile_no & 1) == 0) tile(cb, ncb, j, cms, xa, xb);
-                    else tile(cb, ncb, j, cms, xb, xa);
-                    ++tile_no;
-                } else {
-                    tile(cb, ncb, j, cms, xa, xb);
+                for (int j = 0; j < TC / 32; j += 2) {
+                    const int cbA = c0 + 32 * j, cbB = cbA + 32;
+                    if (cbA >= c_end) break;
+                    const bool hasB = cbB < c_end;
+                    tile(cbA, hasB ? cbB : cbA, j, cms, xa, xb, j == 0 && c0 + TC < c_end);
+                    if (hasB) {
+                        const int after = (j + 2 < TC / 32 && cbB + 32 < c_end) ? cbB + 32 : (c0 + TC < c_end ? c0 + TC : cbB);
+                        tile(cbB, after, j + 1, cms, xb, xa, false);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < TC / 32; ++j) {
+                    const int cb = c0 + 32 * j;
+                    if (cb >= c_end) continue;
+                    tile(cb, cb, j, cms, xa, xb, false);
                 }
             }
         }
         MFCD_STAMP(ts0);
         // this wave's pieces of the next stage have landed: everything but the X prefetch of the stage's last tile,
-        // which is younger than the DMA (vmcnt counts in issue order) and must stay in flight across the barrier
-        if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (pend == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // which is younger than the DMA (vmcnt counts in issue order) and stays in flight across the barrier
+        if (PFX && active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPend) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // ... and everybody's; this buffer may be overwritten
         MFCD_STAMP(ts1);
@@ -679,6 +701,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
 #endif
         buf ^= 1;
     }
+    if constexpr (PFX) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (dummy) request still targets xa / xb
 #if MFCD_UVT_STAMPS
     if (lane == 0 && active) {
         atomicAdd(&mfcd_uvt_dbg[0], cyc_chain);
@@ -771,26 +794,26 @@ __global__ __launch_bounds__(1024) void uvt_final_tiled_kernel(const double *__r
     const int nthr = blockDim.x;   // 256 (one workgroup per 256 rows) or 1024 (single-workgroup form)
     double q = 0.0, e = 0.0;
     for (int r = blockIdx.x * nthr + threadIdx.x; r < n; r += gridDim.x * nthr) {
-        double sx = 0.0;
+        // ONE pass over the splits (independent loads): the sums above are polynomials in mu, so their coefficients are
+        // accumulated first and mu (which needs sum x) is applied at the end, all in f64
+        double sx = 0.0, s_ac = 0.0, s_a = 0.0, s_ax0 = 0.0, aa = 0.0, s_cc = 0.0, s_c = 0.0, s_cx0 = 0.0, s_n = 0.0,
+               s_nx0 = 0.0, s_nx00 = 0.0;
         for (int sp = 0; sp < splits; ++sp) {
             const double *t = part_rows + ((size_t)sp * n + r) * kTiledRowSums;
             const int c0 = sp * cols_per_split;
             const double ns = (double)(min(m, c0 + cols_per_split) - c0);
-            sx += t[3] + ns * t[5];
+            const double t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], x0 = t[5];
+            sx += t3 + ns * x0;
+            s_ac += t0; s_a += t2; s_ax0 += x0 * t2;
+            aa += t1;
+            s_cc += t4; s_c += t3; s_cx0 += x0 * t3;
+            s_n += ns; s_nx0 += ns * x0; s_nx00 += ns * x0 * x0;
         }
         const float xmean = (float)(sx / (double)m);
         const double mu = (double)xmean;
-        double ac = 0.0, aa = 0.0, cc = 0.0, qr = 0.0;
-        for (int sp = 0; sp < splits; ++sp) {
-            const double *t = part_rows + ((size_t)sp * n + r) * kTiledRowSums;
-            const int c0 = sp * cols_per_split;
-            const double ns = (double)(min(m, c0 + cols_per_split) - c0);
-            const double x0 = t[5], sh = mu - x0;
-            ac += t[0] - sh * t[2];
-            aa += t[1];
-            cc += t[4] - 2.0 * sh * t[3] + ns * sh * sh;
-            qr += t[4] + 2.0 * x0 * t[3] + ns * x0 * x0;
-        }
+        const double ac = s_ac - mu * s_a + s_ax0;                                           // sum a (x - mu)
+        const double cc = s_cc - 2.0 * (mu * s_c - s_cx0) + (mu * mu * s_n - 2.0 * mu * s_nx0 + s_nx00);   // sum (x - mu)^2
+        const double qr = s_cc + 2.0 * s_cx0 + s_nx00;                                       // sum x^2
         double *o = row_stats + (size_t)r * 8;
         o[0] = ac; o[1] = aa; o[2] = fmax(0.0, cc); o[3] = (double)rm[r]; o[4] = mu;
         o[5] = qr; o[6] = 0.0; o[7] = 0.0;
@@ -852,15 +875,20 @@ __global__ __launch_bounds__(256) void uvt_scal_kernel(const double *__restrict_
 
 // k rows of UV^T (structure.py:389-392): one wave per (row, 64-column chunk)
 __global__ __launch_bounds__(256) void uvt_rows_kernel(const float *__restrict__ U, const float *__restrict__ V,
-                                                       const int32_t *__restrict__ row_ids, int k, int m, int d,
-                                                       float *__restrict__ out)
+                                                       const int32_t *__restrict__ row_ids, int k, int n, int m,
+                                                       int d, float *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int r = blockIdx.y;
     (void)lane;
     if (r >= k || c >= m) return;
-    const float *ur = U + (int64_t)row_ids[r] * d, *vc = V + (int64_t)c * d;
+    const int row = row_ids[r];
+    if (row < 0 || row >= n) {   // never read outside the table: a bad id shows as a row of NaN
+        out[(int64_t)r * m + c] = __builtin_nanf("");
+        return;
+    }
+    const float *ur = U + (int64_t)row * d, *vc = V + (int64_t)c * d;
     float acc = 0.0f;
     for (int q = 0; q < d; ++q) acc += ur[q] * vc[q];
     out[(int64_t)r * m + c] = acc;
@@ -886,7 +914,7 @@ TiledCfg tiled_cfg(int d)
 {
     switch (d) {
     case 256: return {4, 32};    // 64 KiB of stages: two workgroups (two waves per SIMD) per CU
-    case 128: return {4, 32};
+    case 128: return {4, 64};    // two tiles per stage: the X prefetch alternates between two register sets
     case 64: return {4, 64};
     case 32: return {4, 128};
     default: return {0, 0};
@@ -957,7 +985,7 @@ int launch_tiled(const UvtWs &w, const float *U, const float *V, const float *X,
         hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, WPE, PFX>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
                            w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
     else
-        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, false, WPE, PFX>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
+        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, false, WPE, false>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
                            w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
     return 0;
 }
@@ -999,7 +1027,7 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
         const int64_t rows = (int64_t)n + m;
         const bool merged = (int64_t)(slices_for(n) + slices_for(m)) * d <= 8192;
         if (!merged)
-            hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256, 2), dim3(256), 0, st, w.colpart, n, m, d, w.bar);
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64, 2), dim3(256), 0, st, w.colpart, n, m, d, w.bar);
         const int rpb = 16;
         hipLaunchKernelGGL(centre_vectors_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
                            sizeof(float) * 2 * (size_t)d, st, U, V, w.colpart, merged ? (const float *)nullptr : w.bar, n,
@@ -1008,10 +1036,10 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
     if (tiled) {
         if (d == 256) { const int rc = launch_tiled<256, 4, 32>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
         else if (d == 128 && g_uvt_wpe128 == 3) { const int rc = launch_tiled<128, 4, 32, 3, false>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-        else if (d == 128) { const int rc = launch_tiled<128, 4, 32, 2, true>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
+        else if (d == 128) { const int rc = launch_tiled<128, 4, 64, 2, true>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
         else if (d == 64) { const int rc = launch_tiled<64, 4, 64>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
         else { const int rc = launch_tiled<32, 4, 128>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-        if (n <= 8192) {   // small n: one workgroup finishes the rows AND the two global sums
+        if (n <= 1024) {   // tiny n (one row per thread): one workgroup finishes the rows AND the two global sums
             hipLaunchKernelGGL(uvt_final_tiled_kernel, dim3(1), dim3(1024), 0, st, w.part_rows, w.part_err, w.rm, n, m,
                                w.splits, w.cols_per_split, w.n_err, row_stats, w.blk, s, scal);
             MFCD_HIP_TRY(hipGetLastError());
@@ -1062,7 +1090,7 @@ extern "C" int mfcd_uvt_rows(const float *U, const float *V, const int32_t *row_
     if (k == 0) return 0;
     if (!row_ids) return MFCD_EINVAL;
     hipLaunchKernelGGL(uvt_rows_kernel, dim3((m + 255) / 256, k), dim3(256), 0, (hipStream_t)stream, U, V, row_ids, k,
-                       m, d, out);
+                       n, m, d, out);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }

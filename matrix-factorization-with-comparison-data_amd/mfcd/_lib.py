@@ -34,6 +34,7 @@ SIGNATURES = {
     "mfcd_batch_coefficients": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfcd_apply_step": (_i32, [_vp] * 8 + [_i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _sz, _vp]),
     "mfcd_dense_grad": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mfcd_dense_grad_from_coefficients": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mfcd_adam_dense": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp]),
     "mfcd_dp_unique_id": (_i32, [_vp, _sz]),
     "mfcd_dp_comm_create": (_i32, [_vp, _sz, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)]),

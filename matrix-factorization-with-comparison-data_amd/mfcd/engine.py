@@ -75,6 +75,19 @@ class AdamBinding:
         su, sv = self.opt.state[self.model.U], self.opt.state[self.model.V]
         return U, V, su["exp_avg"], su["exp_avg_sq"], sv["exp_avg"], sv["exp_avg_sq"]
 
+    def call_context(self):
+        """(six raw table pointers, n, m, d, device, dtype) for the C-ABI, computed once per binding: the binding is
+        a view of tensors that stay where they are for its lifetime (`refresh()` after replacing any of them)."""
+        ctx = getattr(self, "_ctx", None)
+        if ctx is None:
+            t = self.tensors()
+            U, V = t[0], t[1]
+            ctx = self._ctx = (tuple(_lib.ptr(x) for x in t), U.shape[0], V.shape[0], U.shape[1], U.device, U.dtype)
+        return ctx
+
+    def refresh(self):
+        self._ctx = None
+
 
 def generate_labels(triplets, X, scale=1.0, K=1, soft=False, seed=0, device=None):
     """BTL labels drawn ON the device (include/mfcd.h: mfcd_generate_labels) → int32 [N, 4] device tensor
@@ -226,8 +239,9 @@ _workspaces = {}   # (device index, stream handle) -> Workspace: one per device 
 
 
 def workspace_for(device):
-    dev = torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lib.stream_ptr(dev))
+    dev = device if isinstance(device, torch.device) else torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(dev).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
         ws = _workspaces[key] = Workspace()
@@ -291,28 +305,28 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None)
     Returns the fp32 device tensor of per-step batch-mean losses.  No host sync — unless `kernel_us`
     (a 3-element list) is given: then the diagnostic twin is used, which brackets every step launch
     with HIP events, waits, and fills kernel_us with [avg, min, max] microseconds (bench.py only)."""
-    import ctypes
     L = _lib.load()
-    U, V, mU, vU, mV, vV = binding.tensors()
-    (n, d), m = U.shape, V.shape[0]
+    ptrs, n, m, d, dev, dtype = binding.call_context()
     N = samples_dev.shape[0]
-    nsteps = n_batches(N, batch_size)
+    nsteps = (N + batch_size - 1) // batch_size
     if loss_out is None:
-        loss_out = torch.empty(max(nsteps, 1), dtype=torch.float32, device=U.device)
+        loss_out = torch.empty(max(nsteps, 1), dtype=torch.float32, device=dev)
     if N == 0:
         return loss_out[:0]
-    ws = workspace_for(U.device).ensure(N, batch_size, n, m, d, U.device)
+    ws = workspace_for(dev).ensure(N, batch_size, n, m, d, dev)
     lr, b1, b2, eps, wd = binding.hyper()
-    args = [_lib.ptr(U), _lib.ptr(V), _lib.ptr(mU), _lib.ptr(vU), _lib.ptr(mV), _lib.ptr(vV),
-            _lib.ptr(samples_dev), N, batch_size, binding.step, n, m, d, lr, b1, b2, eps, wd,
-            _lib.ptr(loss_out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(U.device)]
-    if U.dtype == torch.bfloat16:
+    args = ptrs + (_lib.ptr(samples_dev), N, batch_size, binding.step, n, m, d, lr, b1, b2, eps, wd,
+                   loss_out.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+    if dtype == torch.bfloat16:
         if kernel_us is not None:
             raise NotImplementedError("the timed diagnostic twin exists for fp32 factors only")
         _lib.check(L.mfcd_train_steps_bf16(*args))
     elif kernel_us is None:
-        _lib.check(L.mfcd_train_steps(*args))
+        code = L.mfcd_train_steps(*args)
+        if code:
+            _lib.check(code)
     else:
+        import ctypes
         out = (ctypes.c_float * 3)()
         _lib.check(L.mfcd_train_steps_timed(*args, ctypes.cast(out, ctypes.c_void_p)))
         kernel_us[:] = [float(out[0]), float(out[1]), float(out[2])]
@@ -335,6 +349,95 @@ def eval_batches(U, V, samples_dev, batch_size, want_p=False):
     _lib.check(fn(_lib.ptr(U), _lib.ptr(V), _lib.ptr(samples_dev), N, batch_size, n, m, d,
                                    _lib.ptr(loss), _lib.ptr(corr), _lib.ptr(p), _lib.stream_ptr(U.device)))
     return loss[:nb], corr[:nb], (p[:N] if want_p else None)
+
+
+def dense_grad_from_coefficients(U, V, samples_dev, g):
+    """Dense [n,d], [m,d] fp32 gradients of a scalar loss w.r.t. U, V from g[t] = dLoss/dx_t (include/mfcd.h:
+    mfcd_dense_grad_from_coefficients) — the backward of the forward kernel for ANY loss on its output."""
+    L = _lib.load()
+    (n, d), m = U.shape, V.shape[0]
+    gU, gV = torch.empty_like(U), torch.empty_like(V)
+    _lib.check(L.mfcd_dense_grad_from_coefficients(_lib.ptr(U), _lib.ptr(V), _lib.ptr(samples_dev), _lib.ptr(g),
+                                                   samples_dev.shape[0], n, m, d, _lib.ptr(gU), _lib.ptr(gV),
+                                                   _lib.stream_ptr(U.device)))
+    return gU, gV
+
+
+class TripletForward(torch.autograd.Function):
+    """p_t = sigmoid(U[u_t] . (V[i_t] - V[j_t])) (structure.py:773-795) with an autograd graph: forward is the fused
+    gather + dot + sigmoid kernel, backward is sigmoid_backward (grad * (1 - p) * p, as ATen) followed by the
+    scatter-accumulate kernel, so `loss.backward()` on `model(u, i, j)` works for any loss and any optimiser."""
+
+    @staticmethod
+    def forward(ctx, U, V, rec):
+        N = rec.shape[0]
+        _, _, p = eval_batches(U.detach(), V.detach(), rec, min(max(N, 1), 4096), want_p=True)
+        ctx.save_for_backward(U, V, rec, p)
+        return p
+
+    @staticmethod
+    def backward(ctx, grad_p):
+        U, V, rec, p = ctx.saved_tensors
+        g = (grad_p.float() * (1.0 - p) * p).contiguous()
+        gU, gV = dense_grad_from_coefficients(U.detach(), V.detach(), rec, g)
+        return gU, gV, None
+
+
+def records_from_indices(u, i, j, n, m, device, z=None):
+    """int32 [N, 4] device records from index tensors (any device, any integer dtype); raises IndexError for an index
+    outside the tables, as U[u] / V[i] would (structure.py:787-789).  Python-style negative indices are accepted."""
+    cols = []
+    for t, size, what in ((u, n, "U"), (i, m, "V"), (j, m, "V")):
+        t = torch.as_tensor(t).reshape(-1).to(device=device, dtype=torch.int64)
+        if t.numel() and (int(t.min()) < -size or int(t.max()) >= size):      # one host sync, as the reference's gather
+            raise IndexError(f"index out of range for {what} with {size} rows")
+        cols.append(torch.where(t < 0, t + size, t).to(torch.int32))
+    N = cols[0].numel()
+    zf = torch.zeros(N, dtype=torch.float32, device=device) if z is None else \
+        torch.as_tensor(z).reshape(-1).to(device=device, dtype=torch.float32)
+    return torch.stack(cols + [zf.view(torch.int32)], dim=1).contiguous()
+
+
+def fit_generic(model, train_loader, val_loader, optimizer, num_epochs, progress=None):
+    """The reference's own loop (structure.py:840-868) for optimisers the fused step does not implement (anything but
+    plain torch.optim.Adam): per batch zero_grad, forward kernel, F.binary_cross_entropy, backward (scatter kernel),
+    optimizer.step(), loss.item() — every step a host round trip, as there; batch order and RNG use identical."""
+    import torch.nn.functional as F
+    U, V = model.U, model.V
+    _require_cuda_param(U.data, "model.U")
+    _require_cuda_param(V.data, "model.V")
+    dev, n, m = U.device, U.shape[0], V.shape[0]
+    train = SampleStore.from_loader(train_loader, n, m, dev)
+    val = SampleStore.from_loader(val_loader, n, m, dev)
+    train_losses, val_losses = [], []
+    it = range(num_epochs) if progress is None else progress(range(num_epochs))
+    for _ in it:
+        order, bs = epoch_order(train_loader)
+        rec = train.ordered(order)
+        total, nb = 0.0, 0
+        for off in range(0, rec.shape[0], bs):
+            batch = rec[off:off + bs]
+            optimizer.zero_grad()
+            pred = TripletForward.apply(U, V, batch)
+            loss = F.binary_cross_entropy(pred, batch[:, 3].view(torch.float32))
+            loss.backward()
+            optimizer.step()
+            total += loss.item()
+            nb += 1
+        train_losses.append(total / max(nb, 1))
+        vorder, vbs = epoch_order(val_loader)
+        vl, _, _ = eval_batches(U.data, V.data, val.ordered(vorder), vbs)
+        val_losses.append(python_float_sum(vl.cpu().numpy()) / max(len(vl), 1))
+    return train_losses, val_losses
+
+
+def fused_step_applies(model, optimizer):
+    """True when `optimizer` is what the fused step implements (AdamBinding would accept it)."""
+    try:
+        AdamBinding(model, optimizer)
+        return True
+    except NotImplementedError:
+        return False
 
 
 def python_float_sum(x):

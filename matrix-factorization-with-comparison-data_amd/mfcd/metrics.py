@@ -49,7 +49,11 @@ def uvt_rows(U, V, row_ids):
     """Rows `row_ids` of UV^T as a [k, m] fp32 device tensor (structure.py:389-392 without the full GEMM)."""
     L = _lib.load()
     U, V = U.float().contiguous(), V.float().contiguous()
-    ids = torch.as_tensor(row_ids, dtype=torch.int32).to(U.device).contiguous()
+    host_ids = torch.as_tensor(row_ids).reshape(-1).cpu()
+    if host_ids.numel() and (int(host_ids.min()) < -U.shape[0] or int(host_ids.max()) >= U.shape[0]):
+        raise IndexError(f"row index out of range for U with {U.shape[0]} rows")     # as U[row] would
+    host_ids = torch.where(host_ids < 0, host_ids + U.shape[0], host_ids)
+    ids = host_ids.to(dtype=torch.int32, device=U.device).contiguous()
     k, m = ids.numel(), V.shape[0]
     out = torch.empty((k, m), dtype=torch.float32, device=U.device)
     _lib.check(L.mfcd_uvt_rows(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ids), k, U.shape[0], m, U.shape[1], _lib.ptr(out),

@@ -39,8 +39,8 @@ class MatrixFactorization(nn.Module):
     """BTL comparison model: P(u prefers i over j) = sigmoid(U[u] . (V[i] - V[j])).
 
     Parameters `.U [n_users, d]`, `.V [n_items, d]`, fp32, drawn N(0, 1/d) in this order (ref:770-771).
-    Calling the module evaluates the forward kernel (no autograd graph: training goes through
-    `train_model`, which fuses backward and Adam on the device)."""
+    Calling the module evaluates the forward kernel; `train_model` fuses forward, backward and Adam on the device
+    for torch.optim.Adam and runs the reference's per-batch loop over the same kernels for any other optimiser."""
 
     def __init__(self, n_users, n_items, d, dtype=torch.float32):
         """`dtype=torch.bfloat16` (extension, BASELINE configs[2]) stores the factors in bf16: same fp32 draws,
@@ -51,12 +51,13 @@ class MatrixFactorization(nn.Module):
         self.V = nn.Parameter((torch.randn(n_items, d) / scale).to(dtype))
 
     def forward(self, u, i, j):
-        U, V = self.U.data, self.V.data
-        rows = torch.stack([torch.as_tensor(u).reshape(-1).double().cpu(), torch.as_tensor(i).reshape(-1).double().cpu(),
-                            torch.as_tensor(j).reshape(-1).double().cpu(),
-                            torch.zeros(torch.as_tensor(u).numel(), dtype=torch.float64)], 1).numpy()
-        store = _engine.SampleStore(rows, U.shape[0], V.shape[0], U.device)
-        _, _, p = _engine.eval_batches(U, V, store.dev, max(store.N, 1), want_p=True)
+        """ref:773-795 on the forward kernel.  fp32 factors that require grad get an autograd graph (custom Function:
+        backward = sigmoid backward + the scatter-accumulate kernel), so `loss.backward()` on the result fills
+        `.U.grad` / `.V.grad` as it does in the reference; bf16 factors and no-grad contexts return a plain tensor."""
+        rec = _engine.records_from_indices(u, i, j, self.U.shape[0], self.V.shape[0], self.U.device)
+        if torch.is_grad_enabled() and self.U.dtype == torch.float32 and (self.U.requires_grad or self.V.requires_grad):
+            return _engine.TripletForward.apply(self.U, self.V, rec)
+        _, _, p = _engine.eval_batches(self.U.data, self.V.data, rec, min(max(rec.shape[0], 1), 4096), want_p=True)
         return p
 
 
@@ -77,7 +78,10 @@ def train_model(model, train_loader, val_loader, optimizer, device, num_epochs=1
     _need_gpu(device)
     model.train()
     progress = (lambda it: _tqdm(it, desc="Training Progress")) if _tqdm is not None else None
-    out = _engine.fit(model, train_loader, val_loader, optimizer, num_epochs, progress)
+    if _engine.fused_step_applies(model, optimizer):
+        out = _engine.fit(model, train_loader, val_loader, optimizer, num_epochs, progress)
+    else:   # any other optimiser (or Adam flags the fused step does not implement): the generic loop, same kernels
+        out = _engine.fit_generic(model, train_loader, val_loader, optimizer, num_epochs, progress)
     model.eval()
     return out
 

@@ -29,7 +29,7 @@ def dev():
 
 def resident_applies(n, m, d):
     """Mirror of plan_resident (csrc/resident.hip): d a power of two <= 256 and the state fits the register files."""
-    return 2 <= d <= 256 and (d & (d - 1)) == 0 and (n + m) * d <= 256 * 8 * 64 * 16
+    return 2 <= d <= 256 and (d & (d - 1)) == 0 and (n + m) * d <= 256 * 8 * 64 * 32
 
 
 def local_applies(n, m, d, B=64):
@@ -547,7 +547,9 @@ def test_full_pipeline_reproduces_reference_run_from_seeds(dev):
 
 
 @pytest.mark.parametrize("n,m,d,N", [(4096, 4096, 64, 64 * 200 + 9), (300, 200, 128, 64 * 50), (64, 48, 8, 64 * 60 + 1),
-                                      (1000, 1000, 2, 64 * 40), (6, 5, 16, 64 * 30)])
+                                      (1000, 1000, 2, 64 * 40), (6, 5, 16, 64 * 30),
+                                      (16384, 16384, 128, 64 * 60 + 3),      # C3: 32 registers per array, LDS accumulators
+                                      (8192, 8192, 64, 64 * 50)])            # 16 registers per array
 def test_lookahead_publishing_is_bit_identical(dev, n, m, d, N):
     """Look-ahead publishing only changes WHEN a row is handed over, never its value: the resident kernel with and
     without it must agree bit for bit (small tables make rows recur inside the window, the deferred-publish case)."""
@@ -638,7 +640,10 @@ def test_auto_takes_the_streaming_form_for_very_short_calls(dev):
     plan = engine.train_plan(64 * 1049, 64, 4096, 4096, 64)
     assert plan["form_name"] == "resident" and plan["resident_q"] == 2 and plan["resident_waves"] == 4096
     assert engine.train_plan(1310, 64, 256, 256, 8)["form_name"] == "local"
-    assert engine.train_plan(64 * 1049, 64, 4096, 4096, 64, bf16=True)["form_name"] == "streaming"
+    assert engine.train_plan(64 * 1049, 64, 4096, 4096, 64, bf16=True)["form_name"] == "resident"   # bf16 tables too
+    c3 = engine.train_plan(107373, 64, 16384, 16384, 128, bf16=True)                # BASELINE configs[2]
+    assert (c3["form_name"], c3["resident_q"], c3["resident_waves"]) == ("resident", 32, 2048)
+    assert engine.train_plan(107373, 64, 65536, 65536, 64)["form_name"] == "streaming"             # C4: HBM-bound
 
 
 @pytest.mark.parametrize("name,n,m,d,steps", [
@@ -1036,3 +1041,110 @@ def test_row_sharded_halves_over_a_one_rank_rccl_group(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------
+# (i) boundary B1: autograd-capable forward, generic optimisers, index validation
+# --------------------------------------------------------------------------------------------------
+def test_forward_builds_an_autograd_graph_and_any_optimiser_trains(dev):
+    """MatrixFactorization.forward (structure.py:773-795) must support `loss.backward()` as in the reference; gradients
+    against plain fp32 torch ops of the same formula; `train_model` with SGD (not fused) against the eager torch loop;
+    more samples than one kernel batch; out-of-range indices raise IndexError like U[u]."""
+    import torch.nn.functional as F
+    import structure as S
+    n, m, d, N = 200, 150, 16, 20000
+    rng = np.random.default_rng(2)
+    torch.manual_seed(4)
+    model = S.MatrixFactorization(n, m, d).to(dev)
+    u = torch.from_numpy(rng.integers(0, n, N))
+    i = torch.from_numpy(rng.integers(0, m, N))
+    j = torch.from_numpy((i.numpy() + 1 + rng.integers(0, m - 1, N)) % m)
+    z = torch.from_numpy(rng.integers(0, 2, N).astype(np.float32)).to(dev)
+    p = model(u, i, j)                                   # N > 16384: several kernel batches
+    assert p.shape == (N,) and p.requires_grad
+    loss = F.binary_cross_entropy(p, z)
+    loss.backward()
+    U2 = model.U.detach().clone().requires_grad_(True)
+    V2 = model.V.detach().clone().requires_grad_(True)
+    ud, idd, jd = u.to(dev), i.to(dev), j.to(dev)
+    p2 = torch.sigmoid((U2[ud] * (V2[idd] - V2[jd])).sum(dim=1))
+    F.binary_cross_entropy(p2, z).backward()
+    np.testing.assert_allclose(p.detach().cpu().numpy(), p2.detach().cpu().numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(model.U.grad.cpu().numpy(), U2.grad.cpu().numpy(), rtol=1e-4, atol=2e-7)
+    np.testing.assert_allclose(model.V.grad.cpu().numpy(), V2.grad.cpu().numpy(), rtol=1e-4, atol=2e-7)
+    with torch.no_grad():
+        assert not model(u[:10], i[:10], j[:10]).requires_grad
+    with pytest.raises(IndexError):
+        model(torch.tensor([n]), torch.tensor([0]), torch.tensor([1]))
+    from mfcd import metrics
+    with pytest.raises(IndexError):
+        metrics.uvt_rows(model.U.data, model.V.data, [0, n])
+    # a non-Adam optimiser goes through the generic loop (same kernels), against the eager torch loop
+    rows = np.stack([u.numpy()[:3000], i.numpy()[:3000], j.numpy()[:3000], z.cpu().numpy()[:3000]], 1).astype(np.float64)
+    loader = torch.utils.data.DataLoader(ListDataset(rows), batch_size=64, shuffle=False)
+    torch.manual_seed(5)
+    ma = S.MatrixFactorization(n, m, d).to(dev)
+    Ub, Vb = ma.U.detach().clone().requires_grad_(True), ma.V.detach().clone().requires_grad_(True)
+    opt_a = torch.optim.SGD(ma.parameters(), lr=0.5, momentum=0.9)
+    opt_b = torch.optim.SGD([Ub, Vb], lr=0.5, momentum=0.9)
+    tl, vl = S.train_model(ma, loader, loader, opt_a, dev, num_epochs=2)
+    ref = []
+    rt = torch.from_numpy(rows).to(dev)
+    for _ in range(2):
+        tot = 0.0
+        for off in range(0, 3000, 64):
+            b = rt[off:off + 64]
+            opt_b.zero_grad()
+            pb = torch.sigmoid((Ub[b[:, 0].long()] * (Vb[b[:, 1].long()] - Vb[b[:, 2].long()])).sum(1))
+            lb = F.binary_cross_entropy(pb, b[:, 3].float())
+            lb.backward()
+            opt_b.step()
+            tot += lb.item()
+        ref.append(tot / 47)
+    np.testing.assert_allclose(tl, ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ma.U.detach().cpu().numpy(), Ub.detach().cpu().numpy(), rtol=0, atol=5e-6)
+    assert len(vl) == 2 and vl[1] < vl[0]
+
+
+@pytest.mark.parametrize("n,m,d,steps", [(16384, 16384, 128, 40), (4096, 4096, 64, 120), (2048, 1024, 256, 60)])
+def test_resident_form_with_bf16_factor_tables(dev, orc, n, m, d, steps):
+    """BASELINE configs[2] in the RESIDENT form (first case = its shape: 2048 waves x 32 registers per array, row
+    gradients in LDS): bf16 tables in HBM, fp32 registers rounded to bf16 after every update — the rounding point the
+    oracle defines.  Same acceptance as the streaming bf16 form: almost every element bit-equal to the oracle, the rest
+    within one bf16 ulp; and the fp32 resident run at the same shape against the fp32 oracle."""
+    from mfcd import engine
+    from oracle import oracle as O
+    import structure as S
+    B = 64
+    N = B * steps - 7
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=31 + d)
+    st = _records(u, i, j, z, n, m, dev)
+    Ub, Vb = orc.round_bf16(U0.copy()), orc.round_bf16(V0.copy())
+    model = S.MatrixFactorization(n, m, d, dtype=torch.bfloat16)
+    with torch.no_grad():
+        model.U.copy_(torch.from_numpy(Ub))
+        model.V.copy_(torch.from_numpy(Vb))
+    model = model.to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    engine.set_train_path("resident")
+    try:
+        assert engine.train_plan(N, B, n, m, d, bf16=True)["form_name"] == "resident"
+        loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).cpu().numpy()
+        engine.check_status()
+        m32, o32 = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        loss32 = engine.train_steps(engine.AdamBinding(m32, o32), st.dev, B).cpu().numpy()
+        engine.check_status()
+    finally:
+        engine.set_train_path("auto")
+    ref = O.new_state(Ub, Vb)
+    ref_loss = orc.train_steps(ref, u, i, j, z, B, 0, lr=1e-3, wd=1e-5, threads=8, bf16_factors=True)
+    np.testing.assert_allclose(loss, ref_loss, rtol=0, atol=1e-4)
+    for nm, got in (("U", model.U.data.float().cpu().numpy()), ("V", model.V.data.float().cpu().numpy())):
+        diff = np.abs(got - ref[nm])
+        assert (diff > 0).mean() < 2e-3, f"{nm}: {(diff > 0).mean():.2e} of the elements differ"
+        assert np.all(diff <= np.maximum(np.abs(ref[nm]), 1e-30) * 2.0 ** -7), nm
+    r32 = O.new_state(U0, V0)
+    r32_loss = orc.train_steps(r32, u, i, j, z, B, 0, lr=1e-3, wd=1e-5, threads=8)
+    np.testing.assert_allclose(loss32, r32_loss, rtol=2e-5, atol=2e-6)
+    assert_close_with_rare_outliers(m32.U.data.cpu().numpy(), r32["U"], 2e-6 + 2e-8 * steps, 1e-3, "fp32 resident U")
+    assert_close_with_rare_outliers(m32.V.data.cpu().numpy(), r32["V"], 2e-6 + 2e-8 * steps, 1e-3, "fp32 resident V")

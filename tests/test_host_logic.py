@@ -36,6 +36,8 @@ def test_library_exports_every_declared_symbol():
     assert L.mfcd_train_plan_query(64, 64, 4096, 4096, 64, 0, ctypes.byref(plan)) == 0 and plan.form == 1   # short call
     assert L.mfcd_train_plan_query(67108, 64, 65536, 65536, 64, 0, ctypes.byref(plan)) == 0 and plan.form == 1
     assert L.mfcd_train_plan_query(1310, 64, 256, 256, 8, 0, ctypes.byref(plan)) == 0 and plan.form == 3
+    assert L.mfcd_train_plan_query(107373, 64, 16384, 16384, 128, 1, ctypes.byref(plan)) == 0    # C3, bf16 tables
+    assert (plan.form, plan.resident_q, plan.resident_waves, plan.fast_math) == (2, 32, 2048, 1)
     assert L.mfcd_uvt_workspace_bytes(100, 100, 8) > 0
 
 
