@@ -38,7 +38,9 @@ ADAM_FAST_PLAIN, ADAM_FAST_TRANS = 16, 2
 C2 = dict(n=4096, m=4096, d=64, p=0.01, s=1.0, K=1, B=64, lr=1e-3, wd=1e-5)
 # BASELINE.json configs[3], the configuration named for data parallelism (rehearsal only: --workload C4)
 C4 = dict(n=65536, m=65536, d=64, p=0.0005, s=1.0, K=4, B=64, lr=1e-3, wd=1e-5)
-WORKLOADS = {"C2": C2, "C4": C4}
+# BASELINE.json configs[2] (timing rehearsal: uniform triplets at its count; its margin sampler yields ~11 k, tests use it)
+C3 = dict(n=16384, m=16384, d=128, p=0.001, s=1.0, K=1, B=64, lr=1e-3, wd=1e-5)
+WORKLOADS = {"C2": C2, "C3": C3, "C4": C4}
 
 
 def make_workload(cfg, seed):
@@ -131,12 +133,12 @@ def roofline_record(cfg, plan, period_us, kernel_us=None):
 class Runner:
     """Consumes optimiser steps exactly like mfcd.engine.fit, but in step-counted slices."""
 
-    def __init__(self, cfg, dev, seed):
+    def __init__(self, cfg, dev, seed, dtype=torch.float32):
         import structure as S
         from mfcd import engine
         self.engine, self.cfg, self.dev = engine, cfg, dev
         tr, va, U0, V0 = make_workload(cfg, seed)
-        model = S.MatrixFactorization(cfg["n"], cfg["m"], cfg["d"])
+        model = S.MatrixFactorization(cfg["n"], cfg["m"], cfg["d"], dtype=dtype)
         with torch.no_grad():
             model.U.copy_(torch.from_numpy(U0))
             model.V.copy_(torch.from_numpy(V0))
@@ -176,7 +178,7 @@ class Runner:
             if record:
                 e0, e1 = self._event(), self._event()
                 e0.record()
-            self.engine.train_steps(bind, self.stream[lo:hi], B)
+            self.engine.train_steps(bind, self.stream[lo:hi], B, defer_step=True)
             if record:
                 e1.record()
                 self.train_events.append((e0, e1, take))
@@ -197,6 +199,7 @@ class Runner:
         order = torch.randperm(self.train.N, generator=self.gen)
         stream = self.train.ordered(order)[: launches * B]
         out = [0.0, 0.0, 0.0]
+        self.bind.flush()
         self.engine.train_steps(self.bind, stream, B, kernel_us=out)
         return out
 
@@ -279,7 +282,7 @@ class _StdoutToStderr:
 
 
 def clock_ramp(runner, seconds):
-    """UNTIMED, before the warm-up steps: keep the chip busy for `seconds` with the same fused-step calls on a SCRATCH
+    """UNTIMED, between the warm-up steps and the timed region: keep the chip busy for `seconds` with the same fused-step calls on a SCRATCH
     copy of the model (the measured model and its optimiser are not touched).  A GPU that has sat idle while the host
     prepared the inputs answers its first launches at idle clocks and wake-up latency (measured on this pool: the first
     20-step call after 0.5 s of idling takes 4-5x the time of the fortieth, tools/diag_short_calls.py); a benchmark of
@@ -305,7 +308,7 @@ def clock_ramp(runner, seconds):
     runner.stream, runner.pos, runner.pre.pending = saved[0], saved[1], saved[2]
     runner.gen.set_state(saved[3])
     return {"untimed": True, "seconds": round(time.perf_counter() - t0, 3), "calls": calls,
-            "what": "20-step fused calls on a scratch copy of the model, before the warm-up steps"}
+            "what": "20-step fused calls on a scratch copy of the model, between the warm-up steps and the timed region"}
 
 
 def uvt_record(dev, U2, V2):
@@ -339,6 +342,18 @@ def uvt_record(dev, U2, V2):
                          "frac_of_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TF, 4),
                          "x_read_GBps": round(4.0 * n * m / (us * 1e-6) / 1e9, 1),
                          "finite": bool(torch.isfinite(sc[:2]).all().item())}
+            # the passes the two metric functions actually issue: rows only (compute_alpha_and_norm_ratios) and
+            # global error only (compute_reconstruction_error), mfcd_uvt_stats_select
+            for what, key in ((1, "rows_only"), (2, "error_only")):
+                metrics.uvt_stats(U, V, X, 1.0, what=what)
+                e0.record()
+                for _ in range(reps):
+                    metrics.uvt_stats(U, V, X, 1.0, what=what)
+                e1.record()
+                torch.cuda.synchronize()
+                usw = e0.elapsed_time(e1) * 1e3 / reps
+                out[name][key] = {"pass_us": round(usw, 1),
+                                  "frac_of_mfma_f32_peak": round(2.0 * n * m * d / (usw * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)}
             del X
             torch.cuda.empty_cache()
         except Exception as e:   # a box with less free memory still reports the smaller shapes
@@ -387,7 +402,7 @@ def build_parser():
     ap.add_argument("--no-extras", action="store_true", help="skip the steady_state and uvt records (profiling runs)")
     ap.add_argument("--steady-epochs", type=int, default=5, help="full epochs of the steady_state record (>= 3)")
     ap.add_argument("--clock-ramp", type=float, default=0.3, metavar="SECONDS",
-                    help="untimed busy phase on scratch state before the warm-up steps (0 = none); see clock_ramp()")
+                    help="untimed busy phase on scratch state in front of the timed region (0 = none); see clock_ramp()")
     ap.add_argument("--dp-mode", choices=["native", "allgather", "allreduce", "shard", "selftest"], default=None,
                     help="form of the multi-GPU path (default native: the loop inside libmfcd_hip.so with one RCCL "
                          "all-gather per step, global batch 64*R; allgather / allreduce: the per-step torch.distributed "
@@ -402,6 +417,8 @@ def build_parser():
                     help="experiment knob of include/mfcd.h (mfcd_set_tuning), e.g. --tune resident_lookahead=8; "
                          "tools/ sweeps only, every published number uses the defaults")
     ap.add_argument("--train-path", choices=["auto", "streaming", "resident", "local"], default="auto")
+    ap.add_argument("--factor-dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: factor tables stored as bf16 (BASELINE configs[2]); moments and arithmetic stay fp32")
     return ap
 
 
@@ -444,9 +461,12 @@ def _run(args):
     if args.tune:
         engine.set_tuning(**{k: int(v) for k, v in (kv.split("=", 1) for kv in args.tune)})
     engine.set_train_path(args.train_path)
-    runner = Runner(cfg, dev, args.seed)
-    ramp = clock_ramp(runner, args.clock_ramp) if args.clock_ramp > 0 else None
+    bf16 = args.factor_dtype == "bf16"
+    runner = Runner(cfg, dev, args.seed, torch.bfloat16 if bf16 else torch.float32)
     runner.run(args.warmup)
+    # untimed, on a scratch copy of the model, directly in front of the timed region (the warm-up steps above include the
+    # host-side build of the epoch's record stream, during which the chip idles again)
+    ramp = clock_ramp(runner, args.clock_ramp) if args.clock_ramp > 0 else None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     consumed = runner.run(args.steps, record=True)
@@ -459,11 +479,12 @@ def _run(args):
     period_us = train_ms * 1e3 / max(launches, 1)          # HIP events around the fused-step calls, gaps included
     # the form the timed calls took: the longest call of the timed region decides what the record describes
     longest = max((k for _, _, k in runner.train_events), default=args.steps)
-    plan = engine.train_plan(min(longest * cfg["B"], runner.train.N), cfg["B"], cfg["n"], cfg["m"], cfg["d"])
+    plan = engine.train_plan(min(longest * cfg["B"], runner.train.N), cfg["B"], cfg["n"], cfg["m"], cfg["d"], bf16=bf16)
     out = {
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 6),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (bf16 factor storage)" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"{cfg['name']}: n={cfg['n']} m={cfg['m']} d={cfg['d']} p={cfg['p']} K={cfg['K']} random triplets, "
                                f"B={cfg['B']}, Adam lr=1e-3 wd=1e-5, {runner.steps_per_epoch} steps/epoch + validation "
                                "pass per epoch", "global_batch": cfg["B"],
@@ -486,8 +507,9 @@ def _run(args):
         engine.check_status()
         k_all = sum(k for _, _, k in runner.train_events)
         ev_us = sum(a.elapsed_time(b) for a, b, _ in runner.train_events) * 1e3 / max(k_all, 1)
-        splan = engine.train_plan(runner.train.N, cfg["B"], cfg["n"], cfg["m"], cfg["d"])
-        kavg, kmin, kmax = runner.kernel_sample(launches=min(512, runner.steps_per_epoch))
+        splan = engine.train_plan(runner.train.N, cfg["B"], cfg["n"], cfg["m"], cfg["d"], bf16=bf16)
+        kavg, kmin, kmax = (runner.kernel_sample(launches=min(512, runner.steps_per_epoch)) if not bf16 else
+                            (ev_us, ev_us, ev_us))   # the timed twin exists for fp32 tables only
         out["steady_state"] = {
             "epochs": E, "steps": E * runner.steps_per_epoch, "value": round(got / dts, 1), "unit": "triplet-updates/s",
             "us_per_step_wall": round(dts * 1e6 / (E * runner.steps_per_epoch), 4),

@@ -133,6 +133,7 @@ int mfcd_set_resident_math(int fast);
 #define MFCD_TUNE_RESIDENT_SPIN_LIMIT 5 /* polls before a wave gives up; 0 = default (2^22)                    */
 #define MFCD_TUNE_SHORT_CALL_STEPS 6    /* "auto": calls of fewer steps stream instead (default 3)             */
 #define MFCD_TUNE_UVT_WPE128 7          /* waves per SIMD of the d = 128 UV^T kernel: 2 (default) or 3        */
+#define MFCD_TUNE_STREAM_CHUNKS 8       /* streaming form: 16-byte chunks per thread and array; 0 = auto      */
 int mfcd_set_tuning(int key, int64_t value);
 
 /*
@@ -176,7 +177,7 @@ int mfcd_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float 
  * here and in oracle/mfcd_oracle.c): U [n][d], V [m][d] are bf16 in HBM; each step reads them as such, does all
  * arithmetic and keeps the Adam moments in fp32, and rounds the updated parameters to the nearest bf16 (ties to
  * even) once, when they are written back.  Streaming form (20 bytes per element per step instead of 24) or, where
- * it applies, the resident form (fast Adam flavour): the register copy is rounded after every update, the same
+ * it applies, the resident form: the register copy is rounded after every update, the same
  * rounding point, so both forms agree with the oracle's definition.
  */
 int mfcd_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, float *mV, float *vV,
@@ -319,6 +320,28 @@ size_t mfcd_uvt_workspace_bytes(int n, int m, int d);
 int mfcd_uvt_stats(const float *U, const float *V, const float *X, int n, int m, int d, double s,
                    double *row_stats, double *scal, void *workspace, size_t workspace_bytes,
                    void *stream);
+/*
+ * The same pass computing only what the caller reads: what = 1 the per-row sums (compute_alpha_and_norm_ratios,
+ * structure.py:982-1064; `scal` may be NULL), what = 2 the global sums (compute_reconstruction_error,
+ * structure.py:940-952; `row_stats` may be NULL), what = 3 both (= mfcd_uvt_stats).  The epilogue's vector work shares
+ * its lanes with the fp32 MFMA, so the narrower passes are faster (7 / 4 / 10 packed operations per pair of outputs).
+ */
+int mfcd_uvt_stats_select(const float *U, const float *V, const float *X, int n, int m, int d, double s,
+                          int what, double *row_stats, double *scal, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/*
+ * The pass in row SLABS, for a ground truth kept as factors (X = A B^T at BASELINE C4 / C5 size would be 16 / 7.5 GiB;
+ * SURVEY 8f N3): the caller forms rows [row0, row0 + nrows) of X with a plain library GEMM into X_slab [nrows][m] and
+ * calls this once per slab.  U, V are the FULL tables (the column centring of U V^T needs every row of U);
+ * row_stats_slab [nrows][8] are final for those rows; scal_slab [4] holds this slab's SHARE of the two global sums —
+ * the caller adds the shares (f64, slab order) to get what mfcd_uvt_stats returns.
+ * workspace: mfcd_uvt_slab_workspace_bytes(n, m, d, nrows) for the largest nrows used.
+ */
+size_t mfcd_uvt_slab_workspace_bytes(int n, int m, int d, int nrows);
+int mfcd_uvt_stats_slab(const float *U, const float *V, const float *X_slab, int n, int m, int d, double s,
+                        int what, int row0, int nrows, double *row_stats_slab, double *scal_slab,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * k rows of UV^T: out[r][c] = sum_k U[row_ids[r]][k] * V[c][k]   (structure.py:389-392 computes

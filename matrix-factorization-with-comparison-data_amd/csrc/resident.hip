@@ -121,7 +121,7 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, b
     const int forced_q = g_tune.resident_q;
     const int wpc = g_tune.resident_wpc > 0 ? g_tune.resident_wpc : 16;
     int look = resident_lookahead(N, B, n, m);
-    const bool fast = bf16 ? true : g_resident_math != 0;   // bf16 tables: fast flavour only
+    const bool fast = g_resident_math != 0;
     if (bf16 && look >= 8) look = 4;
     static const int kQ[5] = {1, 2, 4, 16, 32};
     for (int qi = 0; qi < 5; ++qi) {

@@ -1,6 +1,6 @@
 // resident_inst.hip — instantiations of the resident kernel for ONE factor width (-DMFCD_RES_D=<d>), so the
 // widths build in parallel.  Slice sizes: Q in {1, 2, 4, 16, 32} registers per array (64..2048 elements per wave);
-// fp32 tables in both Adam flavours, bf16 tables (BASELINE configs[2]) in the fast flavour.
+// fp32 and bf16 tables (BASELINE configs[2]), both Adam flavours.
 #include "resident_kernel.h"
 
 #ifndef MFCD_RES_D
@@ -22,10 +22,11 @@ bool with_kernel(int look, int fast, int bf16, F fn)
     if constexpr ((64 * Q) % D == 0) {
         using mfcd_detail::resident_train_kernel;
         if (bf16) {
-            if (!fast) return false;   // bf16 tables: fast flavour only
             if (look >= 8) return false;
-            if (look > 0) fn(resident_train_kernel<D, Q, 4, true, true>);
-            else fn(resident_train_kernel<D, Q, 0, true, true>);
+            if (look > 0 && fast) fn(resident_train_kernel<D, Q, 4, true, true>);
+            else if (look > 0) fn(resident_train_kernel<D, Q, 4, false, true>);
+            else if (fast) fn(resident_train_kernel<D, Q, 0, true, true>);
+            else fn(resident_train_kernel<D, Q, 0, false, true>);
             return true;
         }
         if (look >= 8 && fast) fn(resident_train_kernel<D, Q, 8, true, false>);

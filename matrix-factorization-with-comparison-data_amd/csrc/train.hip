@@ -349,7 +349,10 @@ Plan make_plan(const void *const *ptrs, int nptrs, int n, int m, int d)
     pl.vec = al16 ? 4 : 1;
     const int64_t total = (int64_t)(n + m) * d;
     pl.chunks = 1;
-    while (pl.chunks < 8 && total / (256 * pl.vec * pl.chunks) > 2048) pl.chunks *= 2;
+    // at most 4 chunks (16 KiB of each array per workgroup): measured at C3 / C4 / C5 size (profiles/r02_stream_chunks.txt),
+    // 8 chunks cost 4-10 % (fewer workgroups in flight per CU: the per-workgroup LDS tile doubles)
+    while (pl.chunks < 4 && total / (256 * pl.vec * pl.chunks) > 2048) pl.chunks *= 2;
+    if (mfcd_detail::g_tune.stream_chunks) pl.chunks = mfcd_detail::g_tune.stream_chunks;   // experiment knob
     pl.E = 256 * pl.vec * pl.chunks;
     pl.blocksU = (int)(((int64_t)n * d + pl.E - 1) / pl.E);
     pl.blocksV = (int)(((int64_t)m * d + pl.E - 1) / pl.E);
@@ -644,6 +647,10 @@ extern "C" int mfcd_set_tuning(int key, int64_t value)
             t.spin_limit = value == 0 ? mfcd_detail::kSpinLimitDefault : (unsigned)value;
             return 0;
         case MFCD_TUNE_UVT_WPE128: return mfcd_detail::set_uvt_wpe128((int)value);
+        case MFCD_TUNE_STREAM_CHUNKS:
+            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return MFCD_EINVAL;
+            t.stream_chunks = (int)value;
+            return 0;
         case MFCD_TUNE_SHORT_CALL_STEPS:
             if (value < 0 || value > 0x7fffffff) return MFCD_EINVAL;
             t.short_call_steps = (int)value;

@@ -155,6 +155,7 @@ struct Tuning {
     int lookahead = -1;          // -1 auto (4, or 0 for tiny tables), 0 off, 4, 8
     int lds_pad = 0;             // unused dynamic LDS per workgroup (bytes)
     unsigned spin_limit = kSpinLimitDefault;   // polls before a wave gives up and sets the status word
+    int stream_chunks = 0;       // streaming form: 16-byte chunks per thread and array (0 = by table size)
     int short_call_steps = 3;    // "auto": calls of fewer steps than this stream (one launch per step) instead of
                                  // paying the persistent launch's fixed cost
 };

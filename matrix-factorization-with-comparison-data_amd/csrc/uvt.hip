@@ -401,12 +401,15 @@ __device__ __forceinline__ void lds_wait4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d
 // PFX: fetch a tile's X values one tile ahead (needs ~45 more registers: two register sets, two copies of the tile
 // body).  On for d <= 128, where an HBM round trip outlasts a tile's MFMA chain; off for d = 256, whose 128-MFMA chain
 // covers it and whose 128-register operand leaves no room.
-template <int D, int NW, int TC, bool XV, int WPE = 2, bool PFX = (D <= 128)>
+// WHAT: 1 = per-row sums only (compute_alpha_and_norm_ratios never reads the global error), 2 = global error sum only
+// (compute_reconstruction_error never reads the rows), 3 = both.  The epilogue's vector work runs on the lanes the fp32
+// MFMA uses, so what the caller does not need is not computed: 7 / 3 / 10 packed operations per pair of outputs.
+template <int D, int NW, int TC, bool XV, int WPE = 2, bool PFX = (D <= 128), int WHAT = 3>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE)))
 void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ X,
                       const float *__restrict__ rm, const float *__restrict__ cm, int n,
                       int m, float s, int cols_per_split, int splits, int row_blocks, double *__restrict__ part_rows,
-                      double *__restrict__ part_err)
+                      double *__restrict__ part_err, double *__restrict__ part_xx)
 {
     constexpr int CPR = D / 4, PIECES = TC * D / 256, PPW = PIECES / NW, CMW = (TC + 63) / 64, PF = 260;
     static_assert(PIECES % NW == 0 && TC % 32 == 0 && CMW <= NW, "stage must split evenly over the waves");
@@ -492,18 +495,13 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
         // branch-free (a branch here makes the values phi nodes, which the compiler resolves with register copies of
         // loads still in flight, i.e. with a wait): 16-byte pieces clamped to stay inside the row; columns at or past
         // the split's end are masked in the epilogue
-        // With PFX the loads are inline asm: the values stay in flight ACROSS the loop's back edge, where the compiler's
-        // wait insertion gives up counting and drains everything (vmcnt(0)) at the first use; issued from asm it does
-        // not track them at all, and the counted waits below (wait_x) are the only ones.
         if constexpr (XV) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float *src = xrow0 + min(cb + 8 * g + 4 * half, m - 4);
 #if MFCD_UVT_EXP == 1
                 xq[g] = f32x4{(float)cb, 1.f, 2.f, 3.f};
 #else
-                if constexpr (PFX) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xq[g]) : "v"(src) : "memory");
-                else xq[g] = *reinterpret_cast<const f32x4 *>(src);
+                xq[g] = *reinterpret_cast<const f32x4 *>(xrow0 + min(cb + 8 * g + 4 * half, m - 4));
 #endif
             }
         } else {
@@ -511,12 +509,12 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
             for (int r = 0; r < 16; ++r) xq[r >> 2][r & 3] = xrow0[min(cb + tile_row(r, half), m - 1)];
         }
     };
-    static_assert(!PFX || XV, "the prefetch form issues its X loads as 16-byte inline-asm loads");
+    static_assert(!PFX || XV, "the prefetch form is built for 16-byte X pieces (four loads per request)");
     constexpr int kPend = 4;   // vector-memory operations one X prefetch puts in flight
     f32x4 xa[4], xb[4];
     if (PFX && active) load_x(c_begin, xa);
 
-    auto tile = [&](int cb, int ncb, int j, const float *cms, f32x4 (&xq)[4], f32x4 (&xn)[4], bool deep) __attribute__((always_inline)) {
+    auto tile = [&](int cb, int ncb, int j, const float *cms, f32x4 (&xq)[4], f32x4 (&xn)[4]) __attribute__((always_inline)) {
                 const bool full = cb + 32 <= c_end;   // wave-uniform
                 MFCD_STAMP(tt0);
                 asm volatile("" ::: "memory");   // the stage's LDS-DMA (issued above) stays OLDER than this prefetch
@@ -551,10 +549,12 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                         // the tile's 16 column means, under the last 16 MFMAs (inline asm like the fragment reads: a
                         // compiler-visible ds_read would drain every outstanding vector-memory operation first, i.e.
                         // the X values just requested for the NEXT tile)
-                        lds_read16_issue<0>(cq[0], cmaddr);
-                        lds_read16_issue<32>(cq[1], cmaddr);
-                        lds_read16_issue<64>(cq[2], cmaddr);
-                        lds_read16_issue<96>(cq[3], cmaddr);
+                        if constexpr ((WHAT & 2) != 0) {
+                            lds_read16_issue<0>(cq[0], cmaddr);
+                            lds_read16_issue<32>(cq[1], cmaddr);
+                            lds_read16_issue<64>(cq[2], cmaddr);
+                            lds_read16_issue<96>(cq[3], cmaddr);
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < QB; ++q) {
@@ -575,19 +575,12 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                 // x - xm, s*x up into the MFMA chain and with them the wait for the X loads (and, as an LDS-DMA is in
                 // flight, for everything: vmcnt(0)) to the top of the chain
                 // (tied to the accumulator so that it stays behind the last MFMA)
-                if constexpr (PFX) {
-                    // this tile's X values were requested one tile ago; younger than them (and allowed to stay in
-                    // flight) are the next tile's request and, for the first tile of a stage, the next stage's DMA pieces
-                    if (deep)
-                        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3])
-                                     : "n"(PPW + kPend) : "memory");
-                    else
-                        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3])
-                                     : "n"(kPend) : "memory");
-                } else {
-                    asm volatile("" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]));
-                }
-                lds_wait4<0>(cq[0], cq[1], cq[2], cq[3]);
+                // (with PFX the values were requested one tile ago and are compiler-visible loads: the wait the compiler
+                // puts here covers them; hiding them in inline asm with hand-counted waits was tried and was NOT safe —
+                // the register allocator may copy a register it believes ready while the load is still in flight)
+                asm volatile("" : "+v"(acc), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]));
+                if constexpr ((WHAT & 2) != 0) lds_wait4<0>(cq[0], cq[1], cq[2], cq[3]);
+                else cq[0] = cq[1] = cq[2] = cq[3] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 // acc[4g+e] = (U V^T)[myrow][cb + 8g + 4*half + e]; cq[g][e] = the matching column mean
                 float pac, paa, pe, psa, psc, pscc;
                 if (full) {   // two terms per instruction (v_pk_*_f32)
@@ -609,12 +602,15 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                             pe2 += av + cv + ev;
                             continue;
 #endif
-                            pac2 = __builtin_elementwise_fma(av, cv, pac2);
-                            paa2 = __builtin_elementwise_fma(av, av, paa2);
-                            pe2 = __builtin_elementwise_fma(ev, ev, pe2);
-                            psa2 += av;
-                            psc2 += cv;
-                            pscc2 = __builtin_elementwise_fma(cv, cv, pscc2);
+                            if constexpr ((WHAT & 1) != 0) {
+                                pac2 = __builtin_elementwise_fma(av, cv, pac2);
+                                paa2 = __builtin_elementwise_fma(av, av, paa2);
+                                psa2 += av;
+                                psc2 += cv;
+                                pscc2 = __builtin_elementwise_fma(cv, cv, pscc2);
+                            }
+                            if constexpr ((WHAT & 2) != 0) pe2 = __builtin_elementwise_fma(ev, ev, pe2);
+                            if constexpr (WHAT == 2) pscc2 = __builtin_elementwise_fma(x2, x2, pscc2);   // sum x^2 for ||sX||
                         }
                     }
                     pac = pac2.x + pac2.y;
@@ -633,12 +629,15 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                         const float av = ok ? gv - rmv : 0.0f;
                         const float cv = ok ? xv - x0v : 0.0f;
                         const float ev = ok ? (gv - cmv) - s * xv : 0.0f;
-                        pac = fmaf(av, cv, pac);
-                        paa = fmaf(av, av, paa);
-                        pe = fmaf(ev, ev, pe);
-                        psa += av;
-                        psc += cv;
-                        pscc = fmaf(cv, cv, pscc);
+                        if constexpr ((WHAT & 1) != 0) {
+                            pac = fmaf(av, cv, pac);
+                            paa = fmaf(av, av, paa);
+                            psa += av;
+                            psc += cv;
+                            pscc = fmaf(cv, cv, pscc);
+                        }
+                        if constexpr ((WHAT & 2) != 0) pe = fmaf(ev, ev, pe);
+                        if constexpr (WHAT == 2) pscc = ok ? fmaf(xv, xv, pscc) : pscc;
                     }
                 }
                 sac += (double)pac;
@@ -674,10 +673,10 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                     const int cbA = c0 + 32 * j, cbB = cbA + 32;
                     if (cbA >= c_end) break;
                     const bool hasB = cbB < c_end;
-                    tile(cbA, hasB ? cbB : cbA, j, cms, xa, xb, j == 0 && c0 + TC < c_end);
+                    tile(cbA, hasB ? cbB : cbA, j, cms, xa, xb);
                     if (hasB) {
                         const int after = (j + 2 < TC / 32 && cbB + 32 < c_end) ? cbB + 32 : (c0 + TC < c_end ? c0 + TC : cbB);
-                        tile(cbB, after, j + 1, cms, xb, xa, false);
+                        tile(cbB, after, j + 1, cms, xb, xa);
                     }
                 }
             } else {
@@ -685,7 +684,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                 for (int j = 0; j < TC / 32; ++j) {
                     const int cb = c0 + 32 * j;
                     if (cb >= c_end) continue;
-                    tile(cb, cb, j, cms, xa, xb, false);
+                    tile(cb, cb, j, cms, xa, xb);
                 }
             }
         }
@@ -701,7 +700,6 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
 #endif
         buf ^= 1;
     }
-    if constexpr (PFX) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (dummy) request still targets xa / xb
 #if MFCD_UVT_STAMPS
     if (lane == 0 && active) {
         atomicAdd(&mfcd_uvt_dbg[0], cyc_chain);
@@ -722,7 +720,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     if (!rowok) err2 = 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off, MFCD_WAVE);
-    if (half == 0 && rowok) {   // kTiledRowSums doubles per (split, row): sum a c', sum a a, sum a, sum c', sum c'c', x0
+    if ((WHAT & 1) != 0 && half == 0 && rowok) {   // kTiledRowSums doubles per (split, row): sum a c', sum a a, sum a, sum c', sum c'c', x0
         double *o = part_rows + ((size_t)split * n + row0 + l31) * kTiledRowSums;
         o[0] = sac;
         o[1] = saa;
@@ -731,7 +729,13 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
         o[4] = sscc;
         o[5] = (double)x0v;
     }
-    if (lane == 0) part_err[(size_t)split * ((n + 31) / 32) + rt] = err2;
+    if ((WHAT & 2) != 0 && lane == 0) part_err[(size_t)split * ((n + 31) / 32) + rt] = err2;
+    if constexpr (WHAT == 2) {   // error-only pass: sum x^2 of the wave's rows (the other forms get it from the row sums)
+        if (!rowok) sscc = 0.0;       // (the two lane halves of a row were combined above)
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sscc += __shfl_xor(sscc, off, MFCD_WAVE);
+        if (lane == 0) part_xx[(size_t)split * ((n + 31) / 32) + rt] = sscc;
+    }
 }
 
 // row_stats[r][8] from the partials, plus this block's share of the two global sums (fixed order → deterministic):
@@ -785,15 +789,16 @@ __global__ __launch_bounds__(256) void uvt_final_kernel(const double *__restrict
 // scal != nullptr: ONE workgroup does all rows and writes the two global sums itself (small n: saves a launch).
 __global__ __launch_bounds__(1024) void uvt_final_tiled_kernel(const double *__restrict__ part_rows,
                                                               const double *__restrict__ part_err,
+                                                              const double *__restrict__ part_xx,
                                                               const float *__restrict__ rm, int n, int m, int splits,
                                                               int cols_per_split, int n_err,
                                                               double *__restrict__ row_stats, double *__restrict__ blk,
-                                                              double s, double *__restrict__ scal)
+                                                              double s, double *__restrict__ scal, int what)
 {
     __shared__ double red[2][1024];
     const int nthr = blockDim.x;   // 256 (one workgroup per 256 rows) or 1024 (single-workgroup form)
     double q = 0.0, e = 0.0;
-    for (int r = blockIdx.x * nthr + threadIdx.x; r < n; r += gridDim.x * nthr) {
+    for (int r = blockIdx.x * nthr + threadIdx.x; (what & 1) && r < n; r += gridDim.x * nthr) {
         // ONE pass over the splits (independent loads): the sums above are polynomials in mu, so their coefficients are
         // accumulated first and mu (which needs sum x) is applied at the end, all in f64
         double sx = 0.0, s_ac = 0.0, s_a = 0.0, s_ax0 = 0.0, aa = 0.0, s_cc = 0.0, s_c = 0.0, s_cx0 = 0.0, s_n = 0.0,
@@ -821,7 +826,10 @@ __global__ __launch_bounds__(1024) void uvt_final_tiled_kernel(const double *__r
     }
     const int per = (n_err + gridDim.x - 1) / gridDim.x;
     const int k1 = min(n_err, ((int)blockIdx.x + 1) * per);
-    for (int k = blockIdx.x * per + threadIdx.x; k < k1; k += nthr) e += part_err[k];
+    for (int k = blockIdx.x * per + threadIdx.x; (what & 2) && k < k1; k += nthr) {
+        e += part_err[k];
+        if (!(what & 1)) q += part_xx[k];
+    }
     red[0][threadIdx.x] = e;
     red[1][threadIdx.x] = q;
     __syncthreads();
@@ -898,7 +906,7 @@ struct UvtWs {
     double *colpart;  // [2][kSlices][d]
     float *bar;       // [2][d]
     float *rm, *cm, *xm;
-    double *scc, *sxx, *part_rows, *part_err, *blk;
+    double *scc, *sxx, *part_rows, *part_err, *part_xx, *blk, *dummy_rows, *dummy_scal;
     int splits, cols_per_split, n_err, nblk;
     bool tiled;
     size_t bytes;
@@ -968,25 +976,39 @@ UvtWs plan_ws(char *base, int n, int m, int d)
     w.sxx = (double *)take(sizeof(double) * (size_t)n);
     w.part_rows = (double *)take(sizeof(double) * (w.tiled ? kTiledRowSums : 2) * (size_t)n * w.splits);
     w.part_err = (double *)take(sizeof(double) * (size_t)w.n_err);
+    w.part_xx = (double *)take(sizeof(double) * (size_t)w.n_err);
     w.blk = (double *)take(sizeof(double) * 2 * (size_t)w.nblk);
+    w.dummy_rows = (double *)take(sizeof(double) * 8 * (size_t)n);   // output the caller did not ask for (select entry)
+    w.dummy_scal = (double *)take(sizeof(double) * 4);
     w.bytes = off;
     return w;
 }
 
 int g_uvt_wpe128 = 2;   // mfcd_set_tuning(MFCD_TUNE_UVT_WPE128): 2 = X prefetch at 2 waves/SIMD (default), 3 = round-1 form
 
-template <int DD, int NW, int TC, int WPE = 2, bool PFX = (DD <= 128)>
-int launch_tiled(const UvtWs &w, const float *U, const float *V, const float *X, int n, int m, float s, bool xv,
-                 hipStream_t st)
+template <int DD, int NW, int TC, int WPE, bool PFX, int WHAT>
+void launch_tiled_what(const UvtWs &w, const float *U, const float *V, const float *X, int n, int m, float s, bool xv,
+                       hipStream_t st)
 {
     const int row_blocks = (n + NW * 32 - 1) / (NW * 32);
     const unsigned blocks = (unsigned)row_blocks * (w.splits >= 8 ? 8u * ((w.splits + 7) / 8) : (unsigned)w.splits);
     if (xv)
-        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, WPE, PFX>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
-                           w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
+        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, WPE, PFX, WHAT>), dim3(blocks), dim3(NW * 64), 0, st, U, V,
+                           X, w.rm, w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err,
+                           w.part_xx);
     else
-        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, false, WPE, false>), dim3(blocks), dim3(NW * 64), 0, st, U, V, X, w.rm,
-                           w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err);
+        hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, false, WPE, false, WHAT>), dim3(blocks), dim3(NW * 64), 0, st, U,
+                           V, X, w.rm, w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err,
+                           w.part_xx);
+}
+
+template <int DD, int NW, int TC, int WPE = 2, bool PFX = (DD <= 128)>
+int launch_tiled(const UvtWs &w, const float *U, const float *V, const float *X, int n, int m, float s, bool xv,
+                 int what, hipStream_t st)
+{
+    if (what == 1) launch_tiled_what<DD, NW, TC, WPE, PFX, 1>(w, U, V, X, n, m, s, xv, st);
+    else if (what == 2) launch_tiled_what<DD, NW, TC, WPE, PFX, 2>(w, U, V, X, n, m, s, xv, st);
+    else launch_tiled_what<DD, NW, TC, WPE, PFX, 3>(w, U, V, X, n, m, s, xv, st);
     return 0;
 }
 
@@ -1007,53 +1029,64 @@ extern "C" size_t mfcd_uvt_workspace_bytes(int n, int m, int d)
     return plan_ws(nullptr, n, m, d).bytes;
 }
 
-extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, int n, int m, int d, double s,
-                              double *row_stats, double *scal, void *workspace, size_t workspace_bytes, void *stream)
+extern "C" size_t mfcd_uvt_slab_workspace_bytes(int n, int m, int d, int nrows)
 {
-    if (!U || !V || !X || !row_stats || !scal || !workspace || n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D)
-        return MFCD_EINVAL;
-    const UvtWs w = plan_ws((char *)workspace, n, m, d);
-    if (workspace_bytes < w.bytes) return MFCD_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const bool xv = (reinterpret_cast<uintptr_t>(X) & 15u) == 0 && m % 4 == 0;
+    if (n <= 0 || m <= 0 || d <= 0 || nrows <= 0 || nrows > n) return 0;
+    return plan_ws(nullptr, n, m, d).bytes + plan_ws(nullptr, nrows, m, d).bytes;
+}
+
+namespace {
+
+// The pass over rows [row0, row0 + nrows) of U against the slab Xs [nrows][m]; the centring vectors come from ALL n rows
+// of U (wf: the plan for n rows holds rm, cm; ws: the plan for nrows rows holds the slab's partial sums; the two are the
+// same plan when the slab is the whole matrix).
+int run_uvt(const float *U, const float *V, const float *Xs, int n, int m, int d, double s, int what, int row0,
+            int nrows, double *row_stats, double *scal, const UvtWs &wf, const UvtWs &ws, hipStream_t st)
+{
+    const bool xv = (reinterpret_cast<uintptr_t>(Xs) & 15u) == 0 && m % 4 == 0;
     const bool al16 = ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15u) == 0;
-    // fused form: X read ONCE, 5 launches (round 1: 8 launches, X read twice); tables off a 16-byte boundary take the
+    // fused form: X read ONCE, 4-5 launches (round 1: 8 launches, X read twice); tables off a 16-byte boundary take the
     // generic form (the plan's column split suits both)
-    const bool tiled = w.tiled && al16;
+    const bool tiled = ws.tiled && al16;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(slices_for(n > m ? n : m), 2), dim3(256), 0, st, U, V, n, m, d,
-                       w.colpart);
+                       wf.colpart);
     {   // 16 rows per workgroup (4 per wave).  Small tables: every workgroup reduces the few partial sums itself
         // (one launch less); large ones: one small kernel reduces them once.
         const int64_t rows = (int64_t)n + m;
         const bool merged = (int64_t)(slices_for(n) + slices_for(m)) * d <= 8192;
         if (!merged)
-            hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64, 2), dim3(256), 0, st, w.colpart, n, m, d, w.bar);
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64, 2), dim3(256), 0, st, wf.colpart, n, m, d, wf.bar);
         const int rpb = 16;
         hipLaunchKernelGGL(centre_vectors_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
-                           sizeof(float) * 2 * (size_t)d, st, U, V, w.colpart, merged ? (const float *)nullptr : w.bar, n,
-                           m, d, rpb, w.rm, w.cm);
+                           sizeof(float) * 2 * (size_t)d, st, U, V, wf.colpart, merged ? (const float *)nullptr : wf.bar, n,
+                           m, d, rpb, wf.rm, wf.cm);
     }
+    const float *Us = U + (int64_t)row0 * d;
+    UvtWs w = ws;            // the slab's partial-sum arrays, with the full problem's centring vectors
+    w.rm = wf.rm + row0;
+    w.cm = wf.cm;
+    const int nn = nrows;
     if (tiled) {
-        if (d == 256) { const int rc = launch_tiled<256, 4, 32>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-        else if (d == 128 && g_uvt_wpe128 == 3) { const int rc = launch_tiled<128, 4, 32, 3, false>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-        else if (d == 128) { const int rc = launch_tiled<128, 4, 64, 2, true>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-        else if (d == 64) { const int rc = launch_tiled<64, 4, 64>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-        else { const int rc = launch_tiled<32, 4, 128>(w, U, V, X, n, m, (float)s, xv, st); if (rc) return rc; }
-        if (n <= 1024) {   // tiny n (one row per thread): one workgroup finishes the rows AND the two global sums
-            hipLaunchKernelGGL(uvt_final_tiled_kernel, dim3(1), dim3(1024), 0, st, w.part_rows, w.part_err, w.rm, n, m,
-                               w.splits, w.cols_per_split, w.n_err, row_stats, w.blk, s, scal);
+        if (d == 256) { const int rc = launch_tiled<256, 4, 32>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
+        else if (d == 128 && g_uvt_wpe128 == 3) { const int rc = launch_tiled<128, 4, 32, 3, false>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
+        else if (d == 128) { const int rc = launch_tiled<128, 4, 64, 2, true>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
+        else if (d == 64) { const int rc = launch_tiled<64, 4, 64>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
+        else { const int rc = launch_tiled<32, 4, 128>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
+        if (nn <= 1024) {   // tiny n (one row per thread): one workgroup finishes the rows AND the two global sums
+            hipLaunchKernelGGL(uvt_final_tiled_kernel, dim3(1), dim3(1024), 0, st, w.part_rows, w.part_err, w.part_xx, w.rm, nn,
+                               m, w.splits, w.cols_per_split, w.n_err, row_stats, w.blk, s, scal, what);
             MFCD_HIP_TRY(hipGetLastError());
             return 0;
         }
-        hipLaunchKernelGGL(uvt_final_tiled_kernel, dim3(w.nblk), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, n, m,
-                           w.splits, w.cols_per_split, w.n_err, row_stats, w.blk, s, (double *)nullptr);
+        hipLaunchKernelGGL(uvt_final_tiled_kernel, dim3(w.nblk), dim3(256), 0, st, w.part_rows, w.part_err, w.part_xx, w.rm, nn,
+                           m, w.splits, w.cols_per_split, w.n_err, row_stats, w.blk, s, (double *)nullptr, what);
     } else {
         // generic form (any d, tables of fewer than 32 rows): X row statistics from a sweep of their own
-        if (xv) hipLaunchKernelGGL(x_rows_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
-        else hipLaunchKernelGGL(x_rows_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, X, n, m, w.xm, w.scc, w.sxx);
-        const dim3 grid(((n + 31) / 32 + 3) / 4, w.splits);
-#define MFCD_UVT(DD)                                                                                            \
-    hipLaunchKernelGGL((uvt_main_kernel<DD>), grid, dim3(256), 0, st, U, V, X, w.rm, w.cm, w.xm, n, m, d, (float)s, \
+        if (xv) hipLaunchKernelGGL(x_rows_kernel<true>, dim3((nn + 3) / 4), dim3(256), 0, st, Xs, nn, m, w.xm, w.scc, w.sxx);
+        else hipLaunchKernelGGL(x_rows_kernel<false>, dim3((nn + 3) / 4), dim3(256), 0, st, Xs, nn, m, w.xm, w.scc, w.sxx);
+        const dim3 grid(((nn + 31) / 32 + 3) / 4, w.splits);
+#define MFCD_UVT(DD)                                                                                               \
+    hipLaunchKernelGGL((uvt_main_kernel<DD>), grid, dim3(256), 0, st, Us, V, Xs, w.rm, w.cm, w.xm, nn, m, d, (float)s, \
                        w.cols_per_split, w.part_rows, w.part_err)
         if (al16 && d == 8) MFCD_UVT(8);
         else if (al16 && d == 16) MFCD_UVT(16);
@@ -1064,11 +1097,49 @@ extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, in
         else MFCD_UVT(0);
 #undef MFCD_UVT
         hipLaunchKernelGGL(uvt_final_kernel, dim3(w.nblk), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, w.xm,
-                           w.scc, w.sxx, n, w.splits, w.n_err, row_stats, w.blk);
+                           w.scc, w.sxx, nn, w.splits, w.n_err, row_stats, w.blk);
     }
     hipLaunchKernelGGL(uvt_scal_kernel, dim3(1), dim3(256), 0, st, w.blk, w.nblk, s, scal);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+}  // namespace
+
+extern "C" int mfcd_uvt_stats_select(const float *U, const float *V, const float *X, int n, int m, int d, double s,
+                                     int what, double *row_stats, double *scal, void *workspace, size_t workspace_bytes,
+                                     void *stream)
+{
+    if (!U || !V || !X || !workspace || n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D || what < 1 || what > 3)
+        return MFCD_EINVAL;
+    if (((what & 1) && !row_stats) || ((what & 2) && !scal)) return MFCD_EINVAL;
+    const UvtWs w = plan_ws((char *)workspace, n, m, d);
+    if (workspace_bytes < w.bytes) return MFCD_EWORKSPACE;
+    if (!(what & 1)) row_stats = w.dummy_rows;   // not asked for: written to scratch (generic form) or not at all (tiled)
+    if (!(what & 2)) scal = w.dummy_scal;
+    return run_uvt(U, V, X, n, m, d, s, what, 0, n, row_stats, scal, w, w, (hipStream_t)stream);
+}
+
+extern "C" int mfcd_uvt_stats(const float *U, const float *V, const float *X, int n, int m, int d, double s,
+                              double *row_stats, double *scal, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return mfcd_uvt_stats_select(U, V, X, n, m, d, s, 3, row_stats, scal, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mfcd_uvt_stats_slab(const float *U, const float *V, const float *X_slab, int n, int m, int d, double s,
+                                   int what, int row0, int nrows, double *row_stats_slab, double *scal_slab,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!U || !V || !X_slab || !workspace || n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D || what < 1 || what > 3)
+        return MFCD_EINVAL;
+    if (row0 < 0 || nrows <= 0 || (int64_t)row0 + nrows > n) return MFCD_EINVAL;
+    if (((what & 1) && !row_stats_slab) || ((what & 2) && !scal_slab)) return MFCD_EINVAL;
+    const UvtWs wf = plan_ws((char *)workspace, n, m, d);
+    const UvtWs ws = plan_ws((char *)workspace + wf.bytes, nrows, m, d);
+    if (workspace_bytes < wf.bytes + ws.bytes) return MFCD_EWORKSPACE;
+    if (!(what & 1)) row_stats_slab = ws.dummy_rows;
+    if (!(what & 2)) scal_slab = ws.dummy_scal;
+    return run_uvt(U, V, X_slab, n, m, d, s, what, row0, nrows, row_stats_slab, scal_slab, wf, ws, (hipStream_t)stream);
 }
 
 #if MFCD_UVT_STAMPS

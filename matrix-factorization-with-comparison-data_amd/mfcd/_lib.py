@@ -50,6 +50,9 @@ SIGNATURES = {
                                [_vp, _vp, _sz, _vp, _vp]),
     "mfcd_uvt_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mfcd_uvt_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
+    "mfcd_uvt_stats_select": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mfcd_uvt_slab_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "mfcd_uvt_stats_slab": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_uvt_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mfcd_generate_labels": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _dbl, _i32, _i32, ctypes.c_uint64, _vp,
                                      _vp]),
@@ -58,7 +61,7 @@ SIGNATURES = {
 }
 
 TUNE_KEYS = {"resident_q": 1, "resident_wpc": 2, "resident_lookahead": 3, "resident_lds_pad": 4,
-             "resident_spin_limit": 5, "short_call_steps": 6, "uvt_wpe128": 7}
+             "resident_spin_limit": 5, "short_call_steps": 6, "uvt_wpe128": 7, "stream_chunks": 8}
 
 
 class TrainPlan(ctypes.Structure):

@@ -57,14 +57,27 @@ class AdamBinding:
         su, sv = optimizer.state[model.U]["step"], optimizer.state[model.V]["step"]
         if float(su) != float(sv):
             raise NotImplementedError("U and V must have taken the same number of Adam steps")
+        self._pending, self._base = 0, None
 
     @property
     def step(self):
-        return int(float(self.opt.state[self.model.U]["step"]))
+        """Adam steps taken so far: the optimizer's `step` tensor plus the steps counted but not yet written back."""
+        if self._base is None:
+            self._base = int(float(self.opt.state[self.model.U]["step"]))
+        return self._base + self._pending
 
-    def advance(self, k):
-        for p in (self.model.U, self.model.V):
-            self.opt.state[p]["step"] += k
+    def advance(self, k, defer=False):
+        """Count k more optimiser steps.  defer=True (epoch loops): only a Python counter moves and `flush()` writes
+        the optimizer's `step` tensors once at the end (two CPU tensor updates per call are ~4 us of host time)."""
+        self._pending += k
+        if not defer:
+            self.flush()
+
+    def flush(self):
+        if self._pending:
+            for p in (self.model.U, self.model.V):
+                self.opt.state[p]["step"] += self._pending
+        self._pending, self._base = 0, None
 
     def hyper(self):
         g = self.group
@@ -300,7 +313,7 @@ def check_status():
                              "parameters are undefined")
 
 
-def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None):
+def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None, defer_step=False):
     """Run ceil(N/B) optimiser steps over `samples_dev` (int32 [N,4] device records, in order).
     Returns the fp32 device tensor of per-step batch-mean losses.  No host sync — unless `kernel_us`
     (a 3-element list) is given: then the diagnostic twin is used, which brackets every step launch
@@ -330,7 +343,7 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None)
         out = (ctypes.c_float * 3)()
         _lib.check(L.mfcd_train_steps_timed(*args, ctypes.cast(out, ctypes.c_void_p)))
         kernel_us[:] = [float(out[0]), float(out[1]), float(out[2])]
-    binding.advance(nsteps)
+    binding.advance(nsteps, defer_step)
     return loss_out[:nsteps]
 
 
@@ -469,13 +482,14 @@ def fit(model, train_loader, val_loader, optimizer, num_epochs, progress=None):
         pre.start(train, order)
     for e in it:
         stream = pre.take()
-        per_epoch_train.append(train_steps(binding, stream, bs))
+        per_epoch_train.append(train_steps(binding, stream, bs, defer_step=True))
         vorder, vbs = epoch_order(val_loader)           # structure.py:861 iter(val_loader)
         if e + 1 < num_epochs:
             order, bs = epoch_order(train_loader)       # next epoch's structure.py:845
             pre.start(train, order)
         vl, _, _ = eval_batches(U, V, val.ordered(vorder), vbs)
         per_epoch_val.append(vl)
+    binding.flush()
     # one device->host transfer for the whole run (the reference syncs every step at 852); the status word is
     # sticky, so an abort in ANY epoch surfaces here
     check_status()

@@ -25,8 +25,9 @@ def _workspace(nbytes, device):
     return buf
 
 
-def uvt_stats(U, V, X, s=1.0):
-    """→ (row_stats f64 [n,8] on device, scal f64 [4] on device); layout in include/mfcd.h."""
+def uvt_stats(U, V, X, s=1.0, what=3):
+    """→ (row_stats f64 [n,8] on device, scal f64 [4] on device); layout in include/mfcd.h.
+    what = 1: only the per-row sums are computed (scal is None), 2: only the global sums (row_stats is None), 3: both."""
     L = _lib.load()
     if U.dtype == torch.bfloat16:   # bf16 factors: exact widening for the one-off metric pass
         U, V = U.float(), V.float()
@@ -37,12 +38,46 @@ def uvt_stats(U, V, X, s=1.0):
     (n, d), m = U.shape, V.shape[0]
     if X.shape != (n, m):
         raise ValueError(f"X must be [{n},{m}], got {tuple(X.shape)}")
-    row_stats = torch.empty((n, 8), dtype=torch.float64, device=U.device)
-    scal = torch.empty(4, dtype=torch.float64, device=U.device)
+    row_stats = torch.empty((n, 8), dtype=torch.float64, device=U.device) if what & 1 else None
+    scal = torch.empty(4, dtype=torch.float64, device=U.device) if what & 2 else None
     ws = _workspace(L.mfcd_uvt_workspace_bytes(n, m, d), U.device)
-    _lib.check(L.mfcd_uvt_stats(_lib.ptr(U), _lib.ptr(V), _lib.ptr(X), n, m, d, float(s), _lib.ptr(row_stats),
-                                _lib.ptr(scal), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(U.device)))
+    _lib.check(L.mfcd_uvt_stats_select(_lib.ptr(U), _lib.ptr(V), _lib.ptr(X), n, m, d, float(s), int(what),
+                                       _lib.ptr(row_stats), _lib.ptr(scal), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(U.device)))
     return row_stats, scal
+
+
+def uvt_stats_factored(U, V, FX, s=1.0, what=3, slab_rows=4096):
+    """The UV^T pass against a ground truth kept as factors (generation_data.FactoredMatrix, X = A B^T): X is formed
+    `slab_rows` rows at a time by a plain library GEMM and each slab goes through mfcd_uvt_stats_slab, so nothing of size
+    n x m exists (C4: 16 GiB dense, 1 GiB per slab).  Returns what uvt_stats returns."""
+    L = _lib.load()
+    if U.dtype == torch.bfloat16:
+        U, V = U.float(), V.float()
+    U, V = U.contiguous(), V.contiguous()
+    dev = U.device
+    (n, d), m = U.shape, V.shape[0]
+    if tuple(FX.shape) != (n, m):
+        raise ValueError(f"X must be [{n},{m}], got {tuple(FX.shape)}")
+    A, B = FX.A.to(dev), FX.B.to(dev)
+    slab_rows = max(1, min(int(slab_rows), n))
+    row_stats = torch.empty((n, 8), dtype=torch.float64, device=dev) if what & 1 else None
+    scal = torch.zeros(4, dtype=torch.float64, device=dev) if what & 2 else None
+    share = torch.empty(4, dtype=torch.float64, device=dev) if what & 2 else None
+    ws = _workspace(L.mfcd_uvt_slab_workspace_bytes(n, m, d, slab_rows), dev)
+    for r0 in range(0, n, slab_rows):
+        r1 = min(n, r0 + slab_rows)
+        Xs = (A[r0:r1] @ B.t()).contiguous()
+        _lib.check(L.mfcd_uvt_stats_slab(_lib.ptr(U), _lib.ptr(V), _lib.ptr(Xs), n, m, d, float(s), int(what), r0,
+                                         r1 - r0, _lib.ptr(row_stats[r0:r1]) if what & 1 else None, _lib.ptr(share),
+                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+        if what & 2:
+            scal += share                      # f64, slab order: deterministic
+    return row_stats, scal
+
+
+def _is_factored(X):
+    return hasattr(X, "A") and hasattr(X, "B") and not isinstance(X, torch.Tensor)
 
 
 def uvt_rows(U, V, row_ids):
@@ -63,7 +98,7 @@ def uvt_rows(U, V, row_ids):
 
 def reconstruction_error(U, V, X, s):
     """compute_reconstruction_error (structure.py:925-955) → float."""
-    _, scal = uvt_stats(U, V, X, s)
+    _, scal = uvt_stats_factored(U, V, X, s, what=2) if _is_factored(X) else uvt_stats(U, V, X, s, what=2)
     e2, r2 = scal[:2].cpu().tolist()
     return float(np.sqrt(e2) / np.sqrt(r2)) if r2 > 0 else float("nan") if e2 == 0 else float("inf")
 
@@ -166,7 +201,7 @@ def alpha_and_norm_ratios(U, V, X):
     """compute_alpha_and_norm_ratios (structure.py:958-1082) → the same 14-tuple."""
     if U.dtype == torch.bfloat16:
         U, V = U.float(), V.float()
-    row_stats, _ = uvt_stats(U, V, X, 1.0)
+    row_stats, _ = uvt_stats(U, V, X, 1.0, what=1)
     rs = row_stats.cpu().numpy()
     n, m = X.shape
     sac, saa, scc = rs[:, 0], rs[:, 1], rs[:, 2]

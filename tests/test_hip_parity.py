@@ -817,8 +817,14 @@ def test_sampler_streams_at_baseline_full_sizes(dev, orc, name, strategy, n, m, 
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
     else:
         model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
-    loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).cpu().numpy()
-    engine.check_status()
+    # bf16 tables take the resident form at C3 size; its IEEE flavour is the one that must match the oracle to the
+    # bf16 ulp (the fast flavour's allowance: test_resident_form_with_bf16_factor_tables)
+    engine.set_resident_math("ieee" if bf16 else "fast")
+    try:
+        loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).cpu().numpy()
+        engine.check_status()
+    finally:
+        engine.set_resident_math("fast")
     ref = O.new_state(U0, V0)
     ref_loss = orc.train_steps(ref, u, i, j, z, B, 0, lr=1e-3, wd=1e-5, threads=8, bf16_factors=bf16)
     if bf16:
@@ -1110,8 +1116,16 @@ def test_forward_builds_an_autograd_graph_and_any_optimiser_trains(dev):
 def test_resident_form_with_bf16_factor_tables(dev, orc, n, m, d, steps):
     """BASELINE configs[2] in the RESIDENT form (first case = its shape: 2048 waves x 32 registers per array, row
     gradients in LDS): bf16 tables in HBM, fp32 registers rounded to bf16 after every update — the rounding point the
-    oracle defines.  Same acceptance as the streaming bf16 form: almost every element bit-equal to the oracle, the rest
-    within one bf16 ulp; and the fp32 resident run at the same shape against the fp32 oracle."""
+    oracle defines.
+      IEEE flavour: parameters, moments and losses must match the oracle as the streaming bf16 form does (almost every
+        element bit-equal, the rest within one bf16 ulp) — the machinery is exact.
+      fast flavour (default; v_sqrt / Newton-corrected rcp, a few fp32 ulp per update): an fp32 ulp can flip a bf16
+        rounding (2^-8 relative), and Adam turns a flipped input into a move of up to ~lr on the few elements of TOUCHED
+        rows whose gradient nearly cancels (measured with tools/diag_bf16_resident.py: 1.8e-4 of the elements, touched
+        rows only, the oracle reacts the same way to a one-ulp input change).  Accepted: <= 2e-3 of the elements
+        beyond one bf16 ulp, none beyond 5 lr (rows hit again keep diverging for a few steps), mean difference <= 2e-7,
+        untouched rows within one bf16 ulp, losses within 1e-4.
+    Also the fp32 resident run at the same shape against the fp32 oracle."""
     from mfcd import engine
     from oracle import oracle as O
     import structure as S
@@ -1120,31 +1134,102 @@ def test_resident_form_with_bf16_factor_tables(dev, orc, n, m, d, steps):
     U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=31 + d)
     st = _records(u, i, j, z, n, m, dev)
     Ub, Vb = orc.round_bf16(U0.copy()), orc.round_bf16(V0.copy())
-    model = S.MatrixFactorization(n, m, d, dtype=torch.bfloat16)
-    with torch.no_grad():
-        model.U.copy_(torch.from_numpy(Ub))
-        model.V.copy_(torch.from_numpy(Vb))
-    model = model.to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+
+    def run_bf16():
+        model = S.MatrixFactorization(n, m, d, dtype=torch.bfloat16)
+        with torch.no_grad():
+            model.U.copy_(torch.from_numpy(Ub))
+            model.V.copy_(torch.from_numpy(Vb))
+        model = model.to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).cpu().numpy()
+        engine.check_status()
+        return loss, model.U.data.float().cpu().numpy(), model.V.data.float().cpu().numpy()
+
     engine.set_train_path("resident")
     try:
         assert engine.train_plan(N, B, n, m, d, bf16=True)["form_name"] == "resident"
-        loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).cpu().numpy()
-        engine.check_status()
+        engine.set_resident_math("ieee")
+        exact = run_bf16()
+        engine.set_resident_math("fast")
+        fast = run_bf16()
         m32, o32 = _model_from(U0, V0, dev, 1e-3, 1e-5)
         loss32 = engine.train_steps(engine.AdamBinding(m32, o32), st.dev, B).cpu().numpy()
         engine.check_status()
     finally:
+        engine.set_resident_math("fast")
         engine.set_train_path("auto")
     ref = O.new_state(Ub, Vb)
     ref_loss = orc.train_steps(ref, u, i, j, z, B, 0, lr=1e-3, wd=1e-5, threads=8, bf16_factors=True)
-    np.testing.assert_allclose(loss, ref_loss, rtol=0, atol=1e-4)
-    for nm, got in (("U", model.U.data.float().cpu().numpy()), ("V", model.V.data.float().cpu().numpy())):
-        diff = np.abs(got - ref[nm])
-        assert (diff > 0).mean() < 2e-3, f"{nm}: {(diff > 0).mean():.2e} of the elements differ"
-        assert np.all(diff <= np.maximum(np.abs(ref[nm]), 1e-30) * 2.0 ** -7), nm
+    touched = {"U": np.zeros(n, bool), "V": np.zeros(m, bool)}
+    touched["U"][u] = True
+    touched["V"][i] = True
+    touched["V"][j] = True
+    start = {"U": Ub, "V": Vb}
+    for flavour, (loss, gU, gV) in (("ieee", exact), ("fast", fast)):
+        np.testing.assert_allclose(loss, ref_loss, rtol=0, atol=1e-4, err_msg=flavour)
+        for nm, got in (("U", gU), ("V", gV)):
+            diff = np.abs(got - ref[nm])
+            # one bf16 ulp at the magnitude the element HAD: a flipped rounding keeps its absolute size while an element
+            # decays towards zero (dense Adam moves it by ~lr per step), so the ulp of the final value is the wrong ruler
+            ulps = diff / (np.maximum(np.abs(ref[nm]), np.abs(start[nm])) * 2.0 ** -7 + 1e-30)
+            if flavour == "ieee":
+                assert (diff > 0).mean() < 2e-3, f"{nm}: {(diff > 0).mean():.2e} of the elements differ"
+                assert ulps.max() <= 1.0, f"{nm} ieee: {int((ulps > 1).sum())} elements beyond one bf16 ulp, worst {ulps.max():.1f}"
+            else:
+                assert (ulps > 1).mean() <= 2e-3, f"{nm} fast: {(ulps > 1).mean():.2e} of the elements beyond one bf16 ulp"
+                assert diff.max() <= 5e-3, f"{nm} fast: max difference {diff.max():.2e}"      # a few Adam steps (lr = 1e-3)
+                assert diff.mean() <= 2e-7, f"{nm} fast: mean difference {diff.mean():.2e}"
+                assert ulps[~touched[nm]].max(initial=0.0) <= 1.0, f"{nm} fast: an untouched row differs by more than one bf16 ulp"
     r32 = O.new_state(U0, V0)
     r32_loss = orc.train_steps(r32, u, i, j, z, B, 0, lr=1e-3, wd=1e-5, threads=8)
     np.testing.assert_allclose(loss32, r32_loss, rtol=2e-5, atol=2e-6)
     assert_close_with_rare_outliers(m32.U.data.cpu().numpy(), r32["U"], 2e-6 + 2e-8 * steps, 1e-3, "fp32 resident U")
     assert_close_with_rare_outliers(m32.V.data.cpu().numpy(), r32["V"], 2e-6 + 2e-8 * steps, 1e-3, "fp32 resident V")
+
+
+@pytest.mark.parametrize("n,m,d", [(4096, 4096, 64), (1003, 333, 256), (300, 5000, 128), (257, 95, 2), (640, 512, 32)])
+def test_uvt_select_computes_only_what_is_asked_with_the_same_sums(dev, orc, n, m, d):
+    """mfcd_uvt_stats_select: the rows-only pass (what compute_alpha_and_norm_ratios reads) and the error-only pass
+    (what compute_reconstruction_error reads) against the full pass: row sums and the error sum bit-equal (same
+    arithmetic, less of it), ||sX||^2 (a different summation path in the error-only pass) to 1e-6."""
+    from mfcd import metrics
+    rng = np.random.default_rng(n + d)
+    U = torch.from_numpy((rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)).to(dev)
+    V = torch.from_numpy((rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)).to(dev)
+    X = torch.from_numpy((rng.standard_normal((n, m)) * 0.5 + 0.3).astype(np.float32)).to(dev)
+    rs3, sc3 = metrics.uvt_stats(U, V, X, 0.8, what=3)
+    rs1, none1 = metrics.uvt_stats(U, V, X, 0.8, what=1)
+    none2, sc2 = metrics.uvt_stats(U, V, X, 0.8, what=2)
+    assert none1 is None and none2 is None
+    assert torch.equal(rs1, rs3)
+    assert float(sc2[0]) == float(sc3[0])
+    assert float(sc2[1]) == pytest.approx(float(sc3[1]), rel=1e-6)
+    ref_rows, err2, ref2 = orc.uvt_stats(U.cpu().numpy(), V.cpu().numpy(), X.cpu().numpy(), 0.8)
+    assert float(sc2[0]) == pytest.approx(err2, rel=2e-5) and float(sc2[1]) == pytest.approx(ref2, rel=2e-5)
+    np.testing.assert_allclose(rs1[:, 1].cpu().numpy(), ref_rows[:, 1], rtol=2e-5)
+
+
+@pytest.mark.parametrize("n,m,d,dx,slab", [(3000, 2000, 64, 16, 1024), (1111, 777, 128, 8, 500), (700, 300, 8, 4, 256)])
+def test_uvt_pass_over_a_factored_ground_truth_equals_the_dense_pass(dev, n, m, d, dx, slab):
+    """X kept as factors goes through the pass in row slabs (mfcd_uvt_stats_slab).  With the slab's rows
+    formed by the same GEMM, per-row sums and the global sums (added slab by slab in f64) must equal the dense pass to
+    fp32 rounding; compute_reconstruction_error accepts the factored X."""
+    import generation_data as gd
+    import structure as S
+    from mfcd import metrics
+    A, Bf = gd.generate_embedding_factors(n, m, dx, "cpu", generator=torch.Generator().manual_seed(n))
+    FX = gd.FactoredMatrix(A, Bf)
+    torch.manual_seed(1)
+    model = S.MatrixFactorization(n, m, d).to(dev)
+    U, V = model.U.data, model.V.data
+    rs_f, sc_f = metrics.uvt_stats_factored(U, V, FX, 0.9, what=3, slab_rows=slab)
+    # dense X assembled from the SAME slab products
+    X = torch.cat([(A[r0:r0 + slab].to(dev) @ Bf.to(dev).t()) for r0 in range(0, n, slab)])
+    rs_d, sc_d = metrics.uvt_stats(U, V, X, 0.9, what=3)
+    # the slab pass splits the columns by ITS row count, so per-tile fp32 sums group differently: fp32-rounding level
+    a, b = rs_f.cpu().numpy(), rs_d.cpu().numpy()
+    for col in range(6):
+        np.testing.assert_allclose(a[:, col], b[:, col], rtol=2e-5, atol=2e-5 * np.abs(b[:, col]).max(), err_msg=f"row_stats[{col}]")
+    np.testing.assert_allclose(sc_f.cpu().numpy()[:2], sc_d.cpu().numpy()[:2], rtol=2e-6)
+    assert S.compute_reconstruction_error(model, FX, 0.9) == pytest.approx(S.compute_reconstruction_error(model, X, 0.9), rel=2e-6)

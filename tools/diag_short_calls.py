@@ -61,3 +61,30 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 print(f"40 calls back to back: {e0.elapsed_time(e1) * 1e3 / 40:.1f} us per call on the GPU, host {1e6 * (t1 - t0) / 40:.1f} us per call")
 engine.check_status()
+
+# host-side split of one call: Python before / the C-ABI call itself / Python after
+from mfcd import _lib
+L = _lib.load()
+real = L.mfcd_train_steps
+spans = []
+
+
+def timed_entry(*a):
+    t0 = time.perf_counter()
+    rc = real(*a)
+    spans.append((t0, time.perf_counter()))
+    return rc
+
+
+L.mfcd_train_steps = timed_entry
+tot, pre, cabi, post = [], [], [], []
+for c in range(60):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    engine.train_steps(r.bind, stream[(c * K) * B:(c * K + K) * B], B)
+    t1 = time.perf_counter()
+    a, b = spans[-1]
+    tot.append(t1 - t0); pre.append(a - t0); cabi.append(b - a); post.append(t1 - b)
+L.mfcd_train_steps = real
+med = lambda x: sorted(x)[len(x) // 2] * 1e6
+print(f"host split (median of 60): total {med(tot):.1f} us = python before {med(pre):.1f} + C-ABI call {med(cabi):.1f} + python after {med(post):.1f}")
