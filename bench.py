@@ -493,6 +493,16 @@ def _run(args):
     }
     if ramp:
         out["clock_ramp"] = ramp
+    if not bf16:
+        # the dominant kernel alone, for a call of the timed call's length: HIP event pair directly around its launch inside
+        # the library (mfcd_train_steps_timed).  This is the figure a `rocprofv3 --kernel-trace --stats` of the same command
+        # shows as that kernel's average duration; `launch_period_us` above brackets the whole call (prologue and batch-mean
+        # kernels and the gaps between the three launches included) and is what `achieved` is priced on.
+        klen = max(1, min(longest, runner.steps_per_epoch))
+        kavg0, _, _ = runner.kernel_sample(launches=klen)
+        per_launch = 1 if plan["form_name"] == "streaming" else klen      # streaming: one launch per optimiser step
+        out["roofline"]["kernel_only"] = {"steps_per_launch": per_launch, "kernel_launch_us": round(kavg0 * per_launch, 2),
+                                          "kernel_us_per_step": round(kavg0, 4)}
     if not args.no_extras:
         # ---- steady state: whole epochs in this same process (what a training run sees; --steps may be far shorter) ----
         E = max(3, args.steady_epochs)
