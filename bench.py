@@ -317,10 +317,11 @@ def clock_ramp(runner, seconds):
 
 def uvt_record(dev, U2, V2):
     """Dense UV^T metric pass (mfcd_uvt_stats: fp32 MFMA, fused epilogue) timed with HIP events at C2, C3 and C5 sizes:
-    whole pass (every launch of the call), TFLOP/s = 2*n*m*d / time, fraction of the fp32-MFMA peak."""
+    whole pass (every launch of the call, host syncs between groups of passes included), TFLOP/s = 2*n*m*d / time,
+    fraction of the fp32-MFMA peak."""
     from mfcd import metrics
     out = {"peak_TFLOPs": MFMA_F32_PEAK_TF, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "data": "synthetic (Gaussian X, U, V)"}
-    shapes = [("C2", 4096, 4096, 64, 20), ("C3", 16384, 16384, 128, 5), ("C5", 100000, 20000, 256, 3)]
+    shapes = [("C2", 4096, 4096, 64, 100), ("C3", 16384, 16384, 128, 10), ("C5", 100000, 20000, 256, 3)]   # passes per sync
     g = torch.Generator(device=dev).manual_seed(123)
     for name, n, m, d, reps in shapes:
         try:
@@ -332,15 +333,27 @@ def uvt_record(dev, U2, V2):
             X = torch.empty(n, m, device=dev)
             for r0 in range(0, n, 8192):                       # generated in slabs: no second n x m temporary
                 X[r0:r0 + 8192].normal_(0.0, 0.5, generator=g)
-            for _ in range(2):
-                metrics.uvt_stats(U, V, X, 1.0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                rs, sc = metrics.uvt_stats(U, V, X, 1.0)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
+
+            def timed(what):
+                """Average pass time over >= 0.25 s of back-to-back passes, after an untimed 0.25 s of the same (a chip
+                that idled while X was generated runs its first passes 10-25 % slower: tools/exp_uvt_sustained.py)."""
+                res = None
+                for phase in range(2):
+                    t0, k = time.perf_counter(), 0
+                    e0.record()
+                    while True:
+                        for _ in range(reps):
+                            res = metrics.uvt_stats(U, V, X, 1.0, what=what)
+                        k += reps
+                        torch.cuda.synchronize()
+                        if time.perf_counter() - t0 >= 0.25:
+                            break
+                    e1.record()
+                    torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / k, res
+
+            us, (rs, sc) = timed(3)
             tf = 2.0 * n * m * d / (us * 1e-6) / 1e12
             out[name] = {"n": n, "m": m, "d": d, "pass_us": round(us, 1), "TFLOPs": round(tf, 1),
                          "frac_of_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TF, 4),
@@ -349,13 +362,7 @@ def uvt_record(dev, U2, V2):
             # the passes the two metric functions actually issue: rows only (compute_alpha_and_norm_ratios) and
             # global error only (compute_reconstruction_error), mfcd_uvt_stats_select
             for what, key in ((1, "rows_only"), (2, "error_only")):
-                metrics.uvt_stats(U, V, X, 1.0, what=what)
-                e0.record()
-                for _ in range(reps):
-                    metrics.uvt_stats(U, V, X, 1.0, what=what)
-                e1.record()
-                torch.cuda.synchronize()
-                usw = e0.elapsed_time(e1) * 1e3 / reps
+                usw, _ = timed(what)
                 out[name][key] = {"pass_us": round(usw, 1),
                                   "frac_of_mfma_f32_peak": round(2.0 * n * m * d / (usw * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)}
             del X

@@ -29,7 +29,13 @@
 #endif
 #if MFCD_UVT_STAMPS
 __device__ unsigned long long mfcd_uvt_dbg[8];   // chain, epilogue, sync, dma-issue cycles; tiles; waves
+// MFCD_UVT_STAMPS=2: no per-phase stamp (the kernel keeps its timing); only the clock of the stage loop:
+// [6] += shader cycles, [7] += 100 MHz real-time ticks, per wave
+#if MFCD_UVT_STAMPS == 1
 #define MFCD_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define MFCD_STAMP(var) const unsigned long long var = 0
+#endif
 #else
 #define MFCD_STAMP(var)
 #endif
@@ -486,6 +492,9 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
 #if MFCD_UVT_STAMPS
     unsigned long long cyc_chain = 0, cyc_epi = 0, cyc_sync = 0, cyc_dma = 0, n_tiles = 0;
 #endif
+#if MFCD_UVT_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int buf = 0;
     // X values of this lane's row for the tile at column cb: columns cb + 8g + 4*half + {0,1,2,3}, g = 0..3.
     // They are fetched ONE TILE AHEAD (round 1 issued them at the top of their own tile): an HBM round trip is ~2 us,
@@ -708,6 +717,8 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
         atomicAdd(&mfcd_uvt_dbg[3], cyc_dma);
         atomicAdd(&mfcd_uvt_dbg[4], n_tiles);
         atomicAdd(&mfcd_uvt_dbg[5], 1ull);
+        atomicAdd(&mfcd_uvt_dbg[6], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd(&mfcd_uvt_dbg[7], (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0);
     }
 #endif
     if (!active) return;
@@ -929,6 +940,9 @@ TiledCfg tiled_cfg(int d)
     }
 }
 
+int g_uvt_target_wgs = 512;    // mfcd_set_tuning(MFCD_TUNE_UVT_TARGET_WGS): workgroups the tiled form aims for: one round of the chip (two
+                               // per CU), then whatever the L2 rule below adds (C3: 617 us at 1024 workgroups, 639 us at 4096)
+
 UvtWs plan_ws(char *base, int n, int m, int d)
 {
     UvtWs w;
@@ -940,7 +954,7 @@ UvtWs plan_ws(char *base, int n, int m, int d)
         // column count allows) so that the XCD-aware mapping applies
         const int row_blocks = (n + tc.NW * 32 - 1) / (tc.NW * 32);
         const int stages = (m + tc.TC - 1) / tc.TC;
-        int64_t want = (4096 + row_blocks - 1) / row_blocks;
+        int64_t want = (g_uvt_target_wgs + row_blocks - 1) / row_blocks;
         const int64_t by_l2 = ((int64_t)m * d * 4 + (2 << 20) - 1) / (2 << 20);
         if (by_l2 > want) want = by_l2;
         int splits = want <= 1 ? 1 : (int)((want + 7) / 8 * 8);
@@ -1015,6 +1029,13 @@ int launch_tiled(const UvtWs &w, const float *U, const float *V, const float *X,
 }  // namespace
 
 namespace mfcd_detail {
+int set_uvt_target_wgs(int v)
+{
+    if (v < 256 || v > (1 << 20)) return MFCD_EINVAL;
+    g_uvt_target_wgs = v;
+    return 0;
+}
+
 int set_uvt_wpe128(int v)
 {
     if (v != 2 && v != 3) return MFCD_EINVAL;

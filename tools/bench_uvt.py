@@ -13,23 +13,24 @@ for name, n, m, d in [("C1", 256, 256, 8), ("C2", 4096, 4096, 64), ("C3", 16384,
     U = torch.randn(n, d, device=dev) / d ** 0.5
     V = torch.randn(m, d, device=dev) / d ** 0.5
     X = torch.randn(n, m, device=dev) * 0.5
-    metrics.uvt_stats(U, V, X, 1.0); torch.cuda.synchronize()
+    def timed(what, seconds=0.3):
+        """Average pass time over >= `seconds` of back-to-back passes after an untimed stretch of the same length (a chip
+        that idled while X was generated runs its first passes 10-25 % slower: tools/exp_uvt_sustained.py)."""
+        per = max(1, min(200, int(2e9 / (n * m * d) * 40)))
+        for phase in range(2):
+            t0, k = time.perf_counter(), 0
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(per):
+                    metrics.uvt_stats(U, V, X, 1.0, what=what)
+                torch.cuda.synchronize()
+                k += per
+            dt_ = (time.perf_counter() - t0) / k
+        return dt_
     reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        metrics.uvt_stats(U, V, X, 1.0)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    dt = timed(3)
     flops = 2.0 * n * m * d
     bytes_ = 4.0 * n * m + 4.0 * (n + m) * d          # X is read once (round 2: row statistics come out of the sweep)
-    sel = {}
-    for what, key in ((1, "rows"), (2, "err")):        # the passes the two metric functions issue
-        metrics.uvt_stats(U, V, X, 1.0, what=what); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            metrics.uvt_stats(U, V, X, 1.0, what=what)
-        torch.cuda.synchronize()
-        sel[key] = (time.perf_counter() - t1) / reps
+    sel = {"rows": timed(1), "err": timed(2)}          # the passes the two metric functions issue
     # torch reference of the reference's own op sequence for the same quantity (GEMM + centring + norms)
     dt_t = float("nan")
     if not os.environ.get("MFCD_SKIP_TORCH"):
