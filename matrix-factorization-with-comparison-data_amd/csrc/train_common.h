@@ -165,6 +165,7 @@ extern int g_resident_math;
 
 int set_uvt_wpe128(int v);   // uvt.hip
 int set_uvt_target_wgs(int v);   // uvt.hip
+int set_uvt_min_stages(int v);   // uvt.hip
 
 ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, bool bf16 = false);
 int resident_lookahead(int64_t N, int B, int n, int m);

@@ -943,6 +943,8 @@ TiledCfg tiled_cfg(int d)
 int g_uvt_target_wgs = 512;    // mfcd_set_tuning(MFCD_TUNE_UVT_TARGET_WGS): workgroups the tiled form aims for: one round of the chip (two
                                // per CU), then whatever the L2 rule below adds (C3: 617 us at 1024 workgroups, 639 us at 4096)
 
+int g_uvt_min_stages = 8;      // mfcd_set_tuning(MFCD_TUNE_UVT_MIN_STAGES): stages a workgroup sweeps at least
+
 UvtWs plan_ws(char *base, int n, int m, int d)
 {
     UvtWs w;
@@ -960,7 +962,8 @@ UvtWs plan_ws(char *base, int n, int m, int d)
         int splits = want <= 1 ? 1 : (int)((want + 7) / 8 * 8);
         // at least 8 stages per workgroup where the column count allows: the prologue (U fragment, first stage) is worth
         // ~1.5 stages (C2: 8 splits 77.8 us, 32 splits 83.6 us for the whole pass)
-        const int max_splits = stages / 8 > 0 ? stages / 8 : (stages / 2 > 0 ? stages / 2 : 1);
+        const int ms_ = g_uvt_min_stages;
+        const int max_splits = stages / ms_ > 0 ? stages / ms_ : (stages / 2 > 0 ? stages / 2 : 1);
         if (splits > max_splits) splits = max_splits >= 8 ? max_splits / 8 * 8 : max_splits;
         if (splits > 256) splits = 256;
         const int per = (stages + splits - 1) / splits;
@@ -1036,6 +1039,13 @@ int set_uvt_target_wgs(int v)
     return 0;
 }
 
+int set_uvt_min_stages(int v)
+{
+    if (v < 1 || v > 64) return MFCD_EINVAL;
+    g_uvt_min_stages = v;
+    return 0;
+}
+
 int set_uvt_wpe128(int v)
 {
     if (v != 2 && v != 3) return MFCD_EINVAL;
@@ -1093,7 +1103,9 @@ int run_uvt(const float *U, const float *V, const float *Xs, int n, int m, int d
         else if (d == 128) { const int rc = launch_tiled<128, 4, 64, 2, true>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
         else if (d == 64) { const int rc = launch_tiled<64, 4, 64>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
         else { const int rc = launch_tiled<32, 4, 128>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
-        if (nn <= 1024) {   // tiny n (one row per thread): one workgroup finishes the rows AND the two global sums
+        // tiny n (one row per thread), or only the global sums wanted and few enough shares: one workgroup finishes the
+        // rows AND the two global sums (no uvt_scal_kernel launch)
+        if (nn <= 1024 || (what == 2 && w.n_err <= 16384)) {
             hipLaunchKernelGGL(uvt_final_tiled_kernel, dim3(1), dim3(1024), 0, st, w.part_rows, w.part_err, w.part_xx, w.rm, nn,
                                m, w.splits, w.cols_per_split, w.n_err, row_stats, w.blk, s, scal, what);
             MFCD_HIP_TRY(hipGetLastError());
@@ -1120,7 +1132,7 @@ int run_uvt(const float *U, const float *V, const float *Xs, int n, int m, int d
         hipLaunchKernelGGL(uvt_final_kernel, dim3(w.nblk), dim3(256), 0, st, w.part_rows, w.part_err, w.rm, w.xm,
                            w.scc, w.sxx, nn, w.splits, w.n_err, row_stats, w.blk);
     }
-    hipLaunchKernelGGL(uvt_scal_kernel, dim3(1), dim3(256), 0, st, w.blk, w.nblk, s, scal);
+    if (what & 2) hipLaunchKernelGGL(uvt_scal_kernel, dim3(1), dim3(256), 0, st, w.blk, w.nblk, s, scal);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }

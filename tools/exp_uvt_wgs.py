@@ -11,8 +11,8 @@ for name, n, m, d, per in [("C2", 4096, 4096, 64, 200), ("mid", 8192, 8192, 64, 
     U = torch.randn(n, d, device=dev) / d ** 0.5
     V = torch.randn(m, d, device=dev) / d ** 0.5
     X = torch.randn(n, m, device=dev) * 0.5
-    for wgs in (512, 1024, 2048, 4096, 8192):
-        engine.set_tuning(uvt_target_wgs=wgs)
+    for wgs, mst in ((512, 8), (512, 4), (512, 2), (1024, 8), (1024, 4), (1024, 2), (2048, 2), (4096, 8)):
+        engine.set_tuning(uvt_target_wgs=wgs, uvt_min_stages=mst)
         res = []
         for what in (3, 1, 2):
             for phase in range(2):
@@ -23,5 +23,5 @@ for name, n, m, d, per in [("C2", 4096, 4096, 64, 200), ("mid", 8192, 8192, 64, 
                     torch.cuda.synchronize(); k += per
                 dt = (time.perf_counter() - t0) / k
             res.append(dt * 1e6)
-        print(f"{name} target_wgs={wgs:5d}: full {res[0]:8.1f} us  rows {res[1]:8.1f}  err {res[2]:8.1f}  ({2.0*n*m*d/res[0]/1e6/157.3*100:.1f} % of peak)", flush=True)
+        print(f"{name} target_wgs={wgs:5d} min_stages={mst}: full {res[0]:8.1f} us  rows {res[1]:8.1f}  err {res[2]:8.1f}  ({2.0*n*m*d/res[0]/1e6/157.3*100:.1f} % of peak)", flush=True)
     del U, V, X
