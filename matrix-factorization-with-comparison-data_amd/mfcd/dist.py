@@ -351,6 +351,69 @@ def broadcast_state(binding, src=0, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
+def hip_slab_pass(U, V, X_rows, row0, s, what):
+    """Rows [row0, row0 + k) of the UV^T metric pass on this GPU (include/mfcd.h: mfcd_uvt_stats_slab): per-row sums
+    for those rows and this slab's share of the two global sums."""
+    from . import metrics
+    L = _lib.load()
+    U, V, X_rows = U.contiguous(), V.contiguous(), X_rows.contiguous()
+    (n, d), m, k = U.shape, V.shape[0], X_rows.shape[0]
+    rs = torch.empty((k, 8), dtype=torch.float64, device=U.device) if what & 1 else None
+    share = torch.empty(4, dtype=torch.float64, device=U.device) if what & 2 else None
+    ws = metrics._workspace(L.mfcd_uvt_slab_workspace_bytes(n, m, d, k), U.device)
+    _lib.check(L.mfcd_uvt_stats_slab(_lib.ptr(U), _lib.ptr(V), _lib.ptr(X_rows), n, m, d, float(s), int(what), int(row0),
+                                     k, _lib.ptr(rs), _lib.ptr(share), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(U.device)))
+    return rs, share
+
+
+def uvt_stats_sharded(U, V, X_rows, row0, s=1.0, what=3, group=None, slab_pass=hip_slab_pass):
+    """The UV^T metric pass with X sharded by ROW BLOCKS over the ranks ("eval pass shards by row blocks of
+    U/X with an all-reduce of a handful of scalars").  Every rank holds the full U, V (the data-parallel replicas; the
+    column centring of UV^T needs every row of U, which is (n, d), not (n, m)) and rows [row0, row0 + k) of X, k may
+    differ per rank and may be 0.  Per rank: one slab pass over its rows (MFMA work / R).  Exchange: ONE all-gather of
+    the 4-double shares (summed in rank order: deterministic, equal to the slab-ordered single-GPU sum) and, when the
+    per-row sums are asked for, one all-gather of the [k, 8] blocks, padded to the largest k.
+    Returns what metrics.uvt_stats returns — row_stats [n, 8] assembled in row order, scal [4] — on every rank."""
+    world = dist.get_world_size(group)
+    n, k = U.shape[0], X_rows.shape[0]
+    dev = U.device
+    rs = share = None
+    if k:
+        rs, share = slab_pass(U, V, X_rows, row0, s, what)
+    meta = torch.tensor([row0, k], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    spans = [(int(t[0]), int(t[1])) for t in metas]
+    if sorted(a for a, b in spans if b) != [a for a, b in spans if b] or sum(b for _, b in spans) != n:
+        raise ValueError(f"row blocks must tile [0, {n}) in rank order, got {spans}")
+    scal = None
+    if what & 2:
+        mine = share if share is not None else torch.zeros(4, dtype=torch.float64, device=dev)
+        shares = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(shares, mine, group=group)
+        scal = torch.zeros(4, dtype=torch.float64, device=dev)
+        for t in shares:
+            scal += t
+    row_stats = None
+    if what & 1:
+        kmax = max(b for _, b in spans)
+        pad = torch.zeros((kmax, 8), dtype=torch.float64, device=dev)
+        if k:
+            pad[:k] = rs
+        blocks = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(blocks, pad, group=group)
+        row_stats = torch.cat([blk[:b] for blk, (_, b) in zip(blocks, spans)])
+    return row_stats, scal
+
+
+def reconstruction_error_sharded(U, V, X_rows, row0, s, group=None, slab_pass=hip_slab_pass):
+    """structure.py:925-955 with X sharded by row blocks: ||(UV^T - colmean) - sX||_F / ||sX||_F, same value on every rank."""
+    _, scal = uvt_stats_sharded(U, V, X_rows, row0, s, what=2, group=group, slab_pass=slab_pass)
+    import numpy as np
+    e2, r2 = scal[:2].cpu().tolist()
+    return float(np.sqrt(e2) / np.sqrt(r2)) if r2 > 0 else float("nan") if e2 == 0 else float("inf")   # as metrics.reconstruction_error
+
+
 def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
     """bench.py's N>1 leg: weak scaling, per-rank batch cfg['B'], global batch B*world; returns the JSON dict."""
     import time

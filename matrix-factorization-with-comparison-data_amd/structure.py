@@ -380,7 +380,8 @@ def parameter_scan(n=1000, m=1000, d=2, p=0.5, s=1.0, device='cpu', lr=1e-3, wei
                  d1=d1, strategy=strategy, popularity_method=popularity_method, alpha=alpha, soft_label=soft_label,
                  generation=generation)
     grid, lists, synchronised = _normalise_grid({k: given[k] for k in _SCAN_KEYS})
-    if save_path and os.path.exists(save_path):
+    rank, world = _scan_ranks()
+    if save_path and os.path.exists(save_path) and rank == 0:
         print(f"🧹 Removing existing file at {save_path}")
         os.remove(save_path)
     if not linear:
@@ -389,15 +390,19 @@ def parameter_scan(n=1000, m=1000, d=2, p=0.5, s=1.0, device='cpu', lr=1e-3, wei
         configs = [{k: (v[t] if len(v) > 1 else v[0]) for k, v in grid.items()} for t in range(len(lists[0]))]
     else:
         raise ValueError("The linear scan is not possible because the parameters are not synchronized.")
+    def run_one(cfg, dev):
+        print(f"\nRunning experiment with parameters: {cfg}")
+        return run_experiment(n=cfg["n"], m=cfg["m"], d=cfg["d"], p=cfg["p"], s=cfg["s"], device=dev,
+                              lr=cfg["lr"], weight_decay=cfg["weight_decay"], reps=cfg["reps"],
+                              num_epochs=cfg["num_epochs"], open_browser=open_browser, K=cfg["K"], d1=cfg["d1"],
+                              strategy=cfg["strategy"], popularity_method=cfg["popularity_method"],
+                              alpha=cfg["alpha"], soft_label=cfg["soft_label"], generation=cfg["generation"])
+
+    if world > 1:
+        return scan_over_ranks(configs, run_one, rank, world, device, save_path, save_every)
     pending = []
     for cfg in configs:
-        print(f"\nRunning experiment with parameters: {cfg}")
-        results = run_experiment(n=cfg["n"], m=cfg["m"], d=cfg["d"], p=cfg["p"], s=cfg["s"], device=device,
-                                 lr=cfg["lr"], weight_decay=cfg["weight_decay"], reps=cfg["reps"],
-                                 num_epochs=cfg["num_epochs"], open_browser=open_browser, K=cfg["K"], d1=cfg["d1"],
-                                 strategy=cfg["strategy"], popularity_method=cfg["popularity_method"],
-                                 alpha=cfg["alpha"], soft_label=cfg["soft_label"], generation=cfg["generation"])
-        pending.append({"params": cfg, "results": results})
+        pending.append({"params": cfg, "results": run_one(cfg, device)})
         if save_path and save_every and len(pending) >= save_every:
             _append_pickle(save_path, pending)
             pending = []
@@ -405,6 +410,39 @@ def parameter_scan(n=1000, m=1000, d=2, p=0.5, s=1.0, device='cpu', lr=1e-3, wei
         _append_pickle(save_path, pending)
         pending = []
     return pending
+
+
+def _scan_ranks():
+    """(rank, world) when the caller runs one process per GPU under torch.distributed, else (0, 1)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def scan_over_ranks(configs, run_one, rank, world, device, save_path=None, save_every=None, group=None):
+    """the experiments of a scan are independent, so under `torchrun --nproc-per-node R` (one process
+    per GPU, process group initialised by the caller) rank r runs experiments r, r+R, r+2R, ... on ITS GPU and rank 0
+    collects them (one `gather_object` of plain Python results at the end; no data-path collective).  Rank 0 returns /
+    pickles the list in the order of `configs`, exactly as the serial scan would; the other ranks return [].
+    Not reproduced: the serial scan lets the global RNG state run on from one experiment into the next, so an experiment's
+    random data here equals the serial run's only for rank 0's first experiment (seed per experiment for replay)."""
+    import torch.distributed as dist
+    dev = device
+    if isinstance(device, str) and device == "cuda":
+        dev = f"cuda:{int(os.environ.get('LOCAL_RANK', rank)) % max(torch.cuda.device_count(), 1)}"
+    mine = [(k, {"params": configs[k], "results": run_one(configs[k], dev)}) for k in range(rank, len(configs), world)]
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0, group=group)
+    if rank != 0:
+        return []
+    done = [entry for _, entry in sorted((kv for part in gathered for kv in part), key=lambda kv: kv[0])]
+    if not save_path:
+        return done
+    chunk = save_every if save_every else len(done)
+    for a in range(0, len(done), max(chunk, 1)):
+        _append_pickle(save_path, done[a:a + chunk])
+    return []
 
 
 def print_return_structure_types(obj, prefix="root"):

@@ -270,3 +270,104 @@ def test_bench_starts_its_own_ranks_and_relays_one_json_line():
                           "--workload", "no-such-workload"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=300)
     assert bad.returncode != 0
+
+
+def _scan_worker(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import structure as S
+        ran = []
+
+        def fake_experiment(**kw):      # stands in for the GPU experiment: the scan logic is what is under test
+            ran.append(kw["weight_decay"])
+            return {"accuracy": [kw["weight_decay"] * 10.0], "device": kw["device"], "rank": rank}
+
+        S.run_experiment, real = fake_experiment, S.run_experiment
+        try:
+            path = os.path.join(out_dir, "scan.pkl")
+            got = S.parameter_scan(n=8, m=8, d=2, p=0.5, device="cuda:7", weight_decay=[1.0, 2.0, 3.0, 4.0, 5.0],
+                                   save_path=path, save_every=2)
+            in_memory = S.parameter_scan(n=8, m=8, d=2, p=0.5, device="cuda:7", weight_decay=[1.0, 2.0, 3.0])
+        finally:
+            S.run_experiment = real
+        import pickle
+        with open(os.path.join(out_dir, f"scan_r{rank}.pkl"), "wb") as f:
+            pickle.dump({"ran": ran, "returned": got, "in_memory": in_memory}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parameter_scan_spreads_experiments_over_ranks_and_rank0_collects_in_order(tmp_path):
+    """experiments of a scan are independent replicas — rank r runs experiments r, r+R, ...; rank 0 writes the
+    .pkl in the serial order (reference layout, structure.py:183-184) and the other ranks return []."""
+    import pickle
+    world = 2
+    mp.spawn(_scan_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [pickle.load(open(tmp_path / f"scan_r{k}.pkl", "rb")) for k in range(world)]
+    assert r[0]["ran"] == [1.0, 3.0, 5.0, 1.0, 3.0] and r[1]["ran"] == [2.0, 4.0, 2.0]
+    assert r[0]["returned"] == [] and r[1]["returned"] == [] and r[1]["in_memory"] == []
+    saved = pickle.load(open(tmp_path / "scan.pkl", "rb"))
+    assert [e["params"]["weight_decay"] for e in saved] == [1.0, 2.0, 3.0, 4.0, 5.0]
+    assert [e["results"]["rank"] for e in saved] == [0, 1, 0, 1, 0]
+    assert all(set(e) == {"params", "results"} for e in saved)
+    mem = r[0]["in_memory"]
+    assert [e["params"]["weight_decay"] for e in mem] == [1.0, 2.0, 3.0] and [e["results"]["rank"] for e in mem] == [0, 1, 0]
+
+
+def _np_slab_pass(U, V, Xs, row0, s, what):
+    """f64 restatement of one row slab of the UV^T pass (layout of include/mfcd.h: mfcd_uvt_stats_slab), for the
+    sharding logic under test."""
+    M = U.double() @ V.double().t()
+    cm = M.mean(0)
+    k = Xs.shape[0]
+    Ms, Xd = M[row0:row0 + k], Xs.double()
+    a, c = Ms - Ms.mean(1, keepdim=True), Xd - Xd.mean(1, keepdim=True)
+    z = torch.zeros(k, dtype=torch.float64)
+    rs = torch.stack([(a * c).sum(1), (a * a).sum(1), (c * c).sum(1), Ms.mean(1), Xd.mean(1), (Xd * Xd).sum(1), z, z], 1)
+    share = torch.tensor([float((((Ms - cm) - s * Xd) ** 2).sum()), float(s * s * (Xd * Xd).sum()), 0.0, 0.0], dtype=torch.float64)
+    return (rs if what & 1 else None), (share if what & 2 else None)
+
+
+def _uvt_worker(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mfcd import dist as mdist
+        g = torch.Generator().manual_seed(3)
+        n, m, d = 50, 40, 8
+        U, V, X = torch.randn(n, d, generator=g), torch.randn(m, d, generator=g), torch.randn(n, m, generator=g)
+        cuts = [0, 31, 31, 50][: world + 1] if world == 3 else [0, 31, 50]     # world 3: the middle rank owns no row
+        lo, hi = cuts[rank], cuts[rank + 1]
+        rs, sc = mdist.uvt_stats_sharded(U, V, X[lo:hi], lo, 0.7, what=3, group=None, slab_pass=_np_slab_pass)
+        err = mdist.reconstruction_error_sharded(U, V, X[lo:hi], lo, 0.7, slab_pass=_np_slab_pass)
+        _, only = mdist.uvt_stats_sharded(U, V, X[lo:hi], lo, 0.7, what=2, slab_pass=_np_slab_pass)
+        torch.save({"rs": rs, "sc": sc, "err": err, "only": only}, os.path.join(out_dir, f"uvt_r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_block_sharded_uvt_pass_assembles_the_single_pass_result(tmp_path, world):
+    """SURVEY 8e G1, eval pass: X in row blocks over the ranks (one rank may own none), shares summed in rank order, row
+    blocks gathered in row order; every rank ends with the same full result = one pass over all rows."""
+    mp.spawn(_uvt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(3)
+    n, m, d = 50, 40, 8
+    U, V, X = torch.randn(n, d, generator=g), torch.randn(m, d, generator=g), torch.randn(n, m, generator=g)
+    rs_ref, sc_ref = _np_slab_pass(U, V, X, 0, 0.7, 3)
+    for r in range(world):
+        got = torch.load(tmp_path / f"uvt_r{r}.pt")
+        assert got["rs"].shape == (n, 8)
+        torch.testing.assert_close(got["rs"], rs_ref, rtol=1e-12, atol=1e-12)
+        torch.testing.assert_close(got["sc"], sc_ref, rtol=1e-12, atol=0)
+        torch.testing.assert_close(got["only"], got["sc"], rtol=0, atol=0)
+        assert got["err"] == pytest.approx(float(torch.sqrt(sc_ref[0] / sc_ref[1])), rel=1e-12)

@@ -1233,3 +1233,51 @@ def test_uvt_pass_over_a_factored_ground_truth_equals_the_dense_pass(dev, n, m, 
         np.testing.assert_allclose(a[:, col], b[:, col], rtol=2e-5, atol=2e-5 * np.abs(b[:, col]).max(), err_msg=f"row_stats[{col}]")
     np.testing.assert_allclose(sc_f.cpu().numpy()[:2], sc_d.cpu().numpy()[:2], rtol=2e-6)
     assert S.compute_reconstruction_error(model, FX, 0.9) == pytest.approx(S.compute_reconstruction_error(model, X, 0.9), rel=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,d,cuts", [(3000, 2048, 64, [0, 1500, 3000]), (2500, 1000, 128, [0, 700, 700, 2500]),
+                                        (4096, 4096, 64, [0, 512, 1024, 1536, 2048, 2560, 3072, 3584, 4096])])
+def test_row_block_sharded_uvt_pass_rehearsal_and_one_rank_group(dev, orc, n, m, d, cuts):
+    """SURVEY 8e G1 (eval pass): X sharded by row blocks.  Rehearsal in one process: every rank's block through
+    mfcd_uvt_stats_slab, shares added in rank order, against the one-pass result (per-tile fp32 sums group by the slab's
+    own column split: fp32-rounding level, as for the factored form) and against the oracle; then the collective form
+    itself on a one-rank RCCL group, which must reproduce the plain pass's assembly."""
+    import torch.distributed as dist
+    from mfcd import dist as mdist, metrics
+    g = torch.Generator().manual_seed(n + d)
+    U = (torch.randn(n, d, generator=g) / d ** 0.5).to(dev)
+    V = (torch.randn(m, d, generator=g) / d ** 0.5).to(dev)
+    X = (torch.randn(n, m, generator=g) * 0.5 + 0.1).to(dev)
+    rs_d, sc_d = metrics.uvt_stats(U, V, X, 0.9)
+    blocks, scal = [], torch.zeros(4, dtype=torch.float64, device=dev)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        if hi > lo:
+            rs, share = mdist.hip_slab_pass(U, V, X[lo:hi], lo, 0.9, 3)
+            blocks.append(rs)
+            scal += share
+    rs_s = torch.cat(blocks)
+    a, b = rs_s.cpu().numpy(), rs_d.cpu().numpy()
+    for col in range(6):
+        scale = np.abs(b[:, col]).max() + 1e-30
+        assert np.abs(a[:, col] - b[:, col]).max() <= 2e-5 * scale, col
+    np.testing.assert_allclose(scal[:2].cpu().numpy(), sc_d[:2].cpu().numpy(), rtol=2e-6)
+    if n * m <= 4_000_000:
+        ref_rows, err2, ref2 = orc.uvt_stats(U.cpu().numpy(), V.cpu().numpy(), X.cpu().numpy(), 0.9)
+        assert float(scal[0]) == pytest.approx(err2, rel=2e-5) and float(scal[1]) == pytest.approx(ref2, rel=2e-5)
+    created = not dist.is_initialized()
+    if created:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rs1, sc1 = mdist.uvt_stats_sharded(U, V, X, 0, 0.9, what=3)
+        one, share = mdist.hip_slab_pass(U, V, X, 0, 0.9, 3)
+        assert torch.equal(rs1, one) and torch.equal(sc1, share)
+        err = mdist.reconstruction_error_sharded(U, V, X, 0, 0.9)
+        assert err == pytest.approx(metrics.reconstruction_error(U, V, X, 0.9), rel=1e-6)
+        with pytest.raises(ValueError):
+            mdist.uvt_stats_sharded(U, V, X[: n // 2], 0, 0.9)      # blocks must tile all rows
+    finally:
+        if created:
+            dist.destroy_process_group()
