@@ -1243,6 +1243,7 @@ def test_row_block_sharded_uvt_pass_rehearsal_and_one_rank_group(dev, orc, n, m,
     mfcd_uvt_stats_slab, shares added in rank order, against the one-pass result (per-tile fp32 sums group by the slab's
     own column split: fp32-rounding level, as for the factored form) and against the oracle; then the collective form
     itself on a one-rank RCCL group, which must reproduce the plain pass's assembly."""
+    import os
     import torch.distributed as dist
     from mfcd import dist as mdist, metrics
     g = torch.Generator().manual_seed(n + d)
