@@ -425,7 +425,10 @@ void resident_train_kernel(ResidentArgs a)
 #pragma unroll
         for (int r = 0; r < NWIN; ++r) {
             tw[r] = a.cold->touch + (size_t)(ROWWIN ? gws * RPW + r : gws) * KW0;
-            winR[r] = (u64)tw[r][0] << 1;           // j = -1: "batch -1" is empty
+            // (the strings are wave-uniform data, but they are written at the end of this kernel, so the compiler issues
+            // a vector load for them; without the readfirstlane the windows live in VGPRs and every test on them below
+            // becomes exec-mask control flow: that was 56 scalar instructions per wave-step)
+            winR[r] = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)tw[r][0]) << 1;   // j = -1: "batch -1" is empty
         }
         u64 win = winR[0];                          // any of my rows
 #pragma unroll
@@ -620,14 +623,19 @@ void resident_train_kernel(ResidentArgs a)
             for (int r = 0; r < NWIN; ++r) winR[r] >>= 1;
             if (fill < 16) {
 #pragma unroll
-                for (int r = 0; r < NWIN; ++r) winR[r] |= (u64)tw[r][widx] << fill;
+                for (int r = 0; r < NWIN; ++r)
+                    winR[r] |= (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)tw[r][widx]) << fill;
                 ++widx;
                 fill += 32;
             }
             win = winR[0];
 #pragma unroll
             for (int r = 1; r < NWIN; ++r) win |= winR[r];
+#if defined(MFCD_RES_EXP) && MFCD_RES_EXP == 1   // timing experiment (tools/): no per-step scalar load
+            const StepScalars sc_next = sc_cur;
+#else
             const StepScalars sc_next = *sc_ptr++;
+#endif
 
             if constexpr (!GRL) {
 #pragma unroll

@@ -8,6 +8,8 @@ import numpy as np, torch
 import structure as S
 from mfcd import engine
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1:     # e.g. resident_q=4 resident_lookahead=8
+    engine.set_tuning(**{k: int(v) for k, v in (a.split("=") for a in sys.argv[1:])})
 n = m = 4096; d = 64
 for B, N in ((1, 20000), (8, 160000), (64, 67108)):
     model = S.MatrixFactorization(n, m, d).to(dev)
