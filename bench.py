@@ -91,12 +91,18 @@ def algorithmic_valu_cycles_per_step(cfg):
     return regs * (ADAM_FAST_PLAIN * CYC_PLAIN + ADAM_FAST_TRANS * CYC_TRANS)
 
 
-def roofline_record(cfg, plan, period_us, kernel_us=None):
+def roofline_record(cfg, plan, period_us, kernel_us=None, kernel_step_us=None):
     """`roofline` object for the form that actually ran (engine.train_plan), per optimiser step.
-    Streaming form: HBM-bound, achieved = algorithmic bytes / period.  Resident / local forms: the state never leaves
+    Streaming form: HBM-bound, achieved = algorithmic bytes / time.  Resident / local forms: the state never leaves
     registers (LDS), so the byte model does not apply; the bound is vector issue, achieved = the Adam update's own
-    issue cycles / period against 1024 SIMDs x 2.4 GHz, and the HBM-equivalent rate is reported beside it, labelled."""
+    issue cycles / time against 1024 SIMDs x 2.4 GHz, and the HBM-equivalent rate is reported beside it, labelled.
+    `time` is the DOMINANT KERNEL's launch duration per optimiser step (`kernel_step_us`: HIP event pair directly around
+    that launch, mfcd_train_steps_timed) when it was measured, else the whole call's period (`period_us`: event pair
+    around the call, prologue / batch-mean launches and gaps included), which is always reported as `call_level`."""
     abytes = algorithmic_bytes_per_step(cfg)
+    call_period_us = period_us
+    if kernel_step_us:
+        period_us = kernel_step_us
     hbm_equiv = abytes / (period_us * 1e-6) / 1e9
     if plan["form_name"] == "streaming":
         rec = {"bound": "hbm", "achieved": round(hbm_equiv, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -124,7 +130,13 @@ def roofline_record(cfg, plan, period_us, kernel_us=None):
                "traffic_note": "null: no counter pass ran inside this process; offline rocprofv3 --pmc figures for this "
                                "kernel are under profiles/ (README there names the file per round)",
                "kernel": kern}
-    rec["launch_period_us"] = round(period_us, 3)
+    rec["priced_on"] = ("dominant kernel's launch duration / steps per launch (HIP event pair around the launch)"
+                        if kernel_step_us else "whole call period (HIP event pair around the call)")
+    rec["launch_period_us"] = round(call_period_us, 3)
+    full = (abytes / (call_period_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rec["bound"] == "hbm" else \
+        (algorithmic_valu_cycles_per_step(cfg) / (call_period_us * 1e-6) / 1e9 / rec["peak"])
+    rec["call_level"] = {"us_per_step": round(call_period_us, 3), "frac": round(full, 4),
+                         "includes": "every launch of the call (prologue, step kernel, batch mean) and the gaps"}
     if kernel_us is not None:
         rec["kernel_us_event_pairs"] = {k: round(v, 3) for k, v in zip(("avg", "min", "max"), kernel_us)}
     return rec
@@ -509,22 +521,25 @@ def _run(args):
                                f"B={cfg['B']}, Adam lr=1e-3 wd=1e-5, {runner.steps_per_epoch} steps/epoch + validation "
                                "pass per epoch", "global_batch": cfg["B"],
                    "train_samples": runner.train.N, "parallelism": "single", "step_form": plan["form_name"]},
-        "roofline": roofline_record(cfg, plan, period_us),
     }
-    out["roofline"]["period_from"] = ("HIP event pairs around the calls of the timed region" if in_region else
-                                      "HIP event pair around an identical call issued right after the timed region")
-    if ramp:
-        out["clock_ramp"] = ramp
+    kstep = kone = None
     if not bf16:
         # the dominant kernel alone, for a call of the timed call's length: HIP event pair directly around its launch inside
         # the library (mfcd_train_steps_timed).  This is the figure a `rocprofv3 --kernel-trace --stats` of the same command
-        # shows as that kernel's average duration; `launch_period_us` above brackets the whole call (prologue and batch-mean
-        # kernels and the gaps between the three launches included) and is what `achieved` is priced on.
+        # shows as that kernel's average duration, and what `achieved` / `frac` are priced on; `call_level` brackets the
+        # whole call (prologue and batch-mean kernels and the gaps between the three launches included)
         klen = max(1, min(longest, runner.steps_per_epoch))
-        kavg0, _, _ = runner.kernel_sample(launches=klen)
+        kstep, _, _ = runner.kernel_sample(launches=klen)
         per_launch = 1 if plan["form_name"] == "streaming" else klen      # streaming: one launch per optimiser step
-        out["roofline"]["kernel_only"] = {"steps_per_launch": per_launch, "kernel_launch_us": round(kavg0 * per_launch, 2),
-                                          "kernel_us_per_step": round(kavg0, 4)}
+        kone = {"steps_per_launch": per_launch, "kernel_launch_us": round(kstep * per_launch, 2),
+                "kernel_us_per_step": round(kstep, 4)}
+    out["roofline"] = roofline_record(cfg, plan, period_us, kernel_step_us=kstep)
+    out["roofline"]["period_from"] = ("HIP event pairs around the calls of the timed region" if in_region else
+                                      "HIP event pair around an identical call issued right after the timed region")
+    if kone:
+        out["roofline"]["kernel_only"] = kone
+    if ramp:
+        out["clock_ramp"] = ramp
     if not args.no_extras:
         # ---- steady state: whole epochs in this same process (what a training run sees; --steps may be far shorter) ----
         E = max(3, args.steady_epochs)
@@ -546,7 +561,8 @@ def _run(args):
             "epochs": E, "steps": E * runner.steps_per_epoch, "value": round(got / dts, 1), "unit": "triplet-updates/s",
             "us_per_step_wall": round(dts * 1e6 / (E * runner.steps_per_epoch), 4),
             "us_per_step_events": round(ev_us, 4), "includes": "per-epoch shuffle, prologue, validation pass",
-            "step_form": splan["form_name"], "roofline": roofline_record(cfg, splan, ev_us, (kavg, kmin, kmax))}
+            "step_form": splan["form_name"],
+            "roofline": roofline_record(cfg, splan, ev_us, (kavg, kmin, kmax), kernel_step_us=None if bf16 else kavg)}
         out["uvt"] = uvt_record(dev, runner.model.U.data, runner.model.V.data)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.seed)

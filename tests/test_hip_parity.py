@@ -1282,3 +1282,33 @@ def test_row_block_sharded_uvt_pass_rehearsal_and_one_rank_group(dev, orc, n, m,
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_uvt_column_split_knobs_change_the_grouping_not_the_result(dev, orc):
+    """MFCD_TUNE_UVT_TARGET_WGS / MFCD_TUNE_UVT_MIN_STAGES only move the column split: per-row sums and global sums agree
+    to fp32 rounding of the per-tile partial sums across settings, and with the oracle."""
+    from mfcd import engine, metrics
+    n, m, d = 2048, 4096, 64
+    g = torch.Generator().manual_seed(77)
+    U = (torch.randn(n, d, generator=g) / d ** 0.5).to(dev)
+    V = (torch.randn(m, d, generator=g) / d ** 0.5).to(dev)
+    X = (torch.randn(n, m, generator=g) * 0.5 - 0.2).to(dev)
+    ref_rows, err2, ref2 = orc.uvt_stats(U.cpu().numpy(), V.cpu().numpy(), X.cpu().numpy(), 1.1)
+    try:
+        outs = []
+        for wgs, mst in ((512, 8), (4096, 8), (4096, 2), (256, 16)):
+            engine.set_tuning(uvt_target_wgs=wgs, uvt_min_stages=mst)
+            rs, sc = metrics.uvt_stats(U, V, X, 1.1)
+            outs.append((rs.cpu().numpy(), sc.cpu().numpy()))
+            assert float(sc[0]) == pytest.approx(err2, rel=2e-5) and float(sc[1]) == pytest.approx(ref2, rel=2e-5)
+        base_rows, base_sc = outs[0]
+        for rows, sc in outs[1:]:
+            for col in range(6):
+                scale = np.abs(base_rows[:, col]).max() + 1e-30
+                assert np.abs(rows[:, col] - base_rows[:, col]).max() <= 2e-5 * scale, col
+            np.testing.assert_allclose(sc[:2], base_sc[:2], rtol=2e-6)
+        with pytest.raises(Exception):
+            engine.set_tuning(uvt_target_wgs=1)
+    finally:
+        engine.set_tuning(uvt_target_wgs=512, uvt_min_stages=8)

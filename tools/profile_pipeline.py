@@ -10,7 +10,9 @@ import structure as S
 
 dev = "cuda"
 cases = {"C1": dict(n=256, m=256, d=8, p=0.05, epochs=30), "nb": dict(n=1000, m=1000, d=2, p=0.5, epochs=30),
-         "nb20": dict(n=1000, m=1000, d=20, p=0.1, epochs=30), "C2": dict(n=4096, m=4096, d=64, p=0.01, epochs=30)}
+         "nb20": dict(n=1000, m=1000, d=20, p=0.1, epochs=30), "C2": dict(n=4096, m=4096, d=64, p=0.01, epochs=30),
+         "C3": dict(n=16384, m=16384, d=128, p=0.001, epochs=3, strategy="margin", reps=1),
+         "C3r": dict(n=16384, m=16384, d=128, p=0.001, epochs=3, strategy="random", reps=1)}
 want = sys.argv[1:] or list(cases)
 
 
@@ -30,11 +32,12 @@ class T:
 for name in want:
     c = cases[name]
     n, m, d, p, epochs = c["n"], c["m"], c["d"], c["p"], c["epochs"]
-    for rep in range(2):   # rep 0 warms caches / lazy init
+    strategy = c.get("strategy", "random")
+    for rep in range(c.get("reps", 2)):   # rep 0 warms caches / lazy init
         torch.manual_seed(rep); np.random.seed(rep)
         t = T()
         X = t("generate_X", lambda: S.generate_X(n, m, d, dev))
-        loaders = t("split_dataset (sample+label)", lambda: S.split_dataset_from_triplets(X, int(n * m * p / 2)))
+        loaders = t("split_dataset (sample+label)", lambda: S.split_dataset_from_triplets(X, int(n * m * p / 2), strategy=strategy))
         tr, va, te = loaders
         model = S.MatrixFactorization(n, m, d).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
