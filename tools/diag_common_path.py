@@ -8,9 +8,13 @@ import numpy as np, torch
 import structure as S
 from mfcd import engine
 dev = torch.device("cuda:0")
-if len(sys.argv) > 1:     # e.g. resident_q=4 resident_lookahead=8
-    engine.set_tuning(**{k: int(v) for k, v in (a.split("=") for a in sys.argv[1:])})
+size = [a for a in sys.argv[1:] if "=" not in a]
+knobs = [a for a in sys.argv[1:] if "=" in a]
+if knobs:     # e.g. resident_q=4 resident_lookahead=8
+    engine.set_tuning(**{k: int(v) for k, v in (a.split("=") for a in knobs)})
 n = m = 4096; d = 64
+if size and size[0] == "C3":
+    n = m = 16384; d = 128
 for B, N in ((1, 20000), (8, 160000), (64, 67108)):
     model = S.MatrixFactorization(n, m, d).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
@@ -22,4 +26,4 @@ for B, N in ((1, 20000), (8, 160000), (64, 67108)):
     engine.train_steps(bind, st.dev, B); torch.cuda.synchronize()
     t0 = time.perf_counter(); engine.train_steps(bind, st.dev, B); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     steps = (N + B - 1) // B
-    print(f"B={B:3d}: {steps} steps, {dt/steps*1e6:.3f} us/step ({3*B} row hits per step over 4096 waves)", flush=True)
+    print(f"B={B:3d}: {steps} steps, {dt/steps*1e6:.3f} us/step ({3*B} row hits per step; n=m={n} d={d})", flush=True)
