@@ -13,7 +13,7 @@ for name, n, m, d in [("C1", 256, 256, 8), ("C2", 4096, 4096, 64), ("C3", 16384,
     U = torch.randn(n, d, device=dev) / d ** 0.5
     V = torch.randn(m, d, device=dev) / d ** 0.5
     X = torch.randn(n, m, device=dev) * 0.5
-    def timed(what, seconds=0.3):
+    def timed(what, seconds=float(os.environ.get("UVT_BENCH_SECONDS", "0.3"))):
         """Average pass time over >= `seconds` of back-to-back passes after an untimed stretch of the same length (a chip
         that idled while X was generated runs its first passes 10-25 % slower: tools/exp_uvt_sustained.py)."""
         per = max(1, min(200, int(2e9 / (n * m * d) * 40)))

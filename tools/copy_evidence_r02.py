@@ -20,7 +20,8 @@ for name in ("bench_c2_default.json", "bench_c2_driver_cmd.json", "bench_c2_driv
              "bench_c2_dp_native_one_rank.json", "bench_c2_shard_one_rank.json", "bench_c4_shard_one_rank.json",
              "uvt_pass_roofline.txt", "metric_functions_c2.txt", "step_period_by_size.txt", "short_call_breakdown.txt",
              "tiny_problem_forms.txt", "resident_pmc_c2.txt", "resident_pmc_c3.txt", "streaming_pmc_C4.txt",
-             "streaming_pmc_C5.txt"):
+             "streaming_pmc_C5.txt", "resident_common_path.txt", "uvt_pass_vs_load_history.txt",
+             "driver_call_event_pair_cost.txt", "valu_issue_microbench.txt"):
     if os.path.exists(os.path.join(E, name)):
         cp(os.path.join(E, name), "r02_" + name)
 subprocess.run([sys.executable, "tools/pmc_traffic.py", f"{E}/pmc_c2_fetch", f"{E}/pmc_c2_write", "profiles/r02_pmc_traffic.json"],

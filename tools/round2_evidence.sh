@@ -19,6 +19,10 @@ timeout -k 10 300 python tools/bench_metrics.py > $E/metric_functions_c2.txt 2>&
 timeout -k 10 300 python tools/bench_sizes.py > $E/step_period_by_size.txt 2>&1; cat $E/step_period_by_size.txt | cut -c1-200
 timeout -k 10 300 python tools/diag_short_calls.py 20 > $E/short_call_breakdown.txt 2>&1; tail -5 $E/short_call_breakdown.txt
 timeout -k 10 300 python tools/bench_forms_tiny.py > $E/tiny_problem_forms.txt 2>&1; tail -8 $E/tiny_problem_forms.txt
+timeout -k 10 300 python tools/diag_common_path.py > $E/resident_common_path.txt 2>&1; timeout -k 10 300 python tools/diag_common_path.py C3 >> $E/resident_common_path.txt 2>&1; grep "B=" $E/resident_common_path.txt
+timeout -k 10 300 python tools/exp_uvt_sustained.py > $E/uvt_pass_vs_load_history.txt 2>&1; grep -v amdgpu.ids $E/uvt_pass_vs_load_history.txt
+timeout -k 10 300 python tools/exp_driver_call.py 20 > $E/driver_call_event_pair_cost.txt 2>&1; grep record $E/driver_call_event_pair_cost.txt
+timeout -k 10 120 tools/microbench/valu_rate > $E/valu_issue_microbench.txt 2>&1; head -3 $E/valu_issue_microbench.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 P="rocprofv3 --kernel-trace --output-format csv"
@@ -26,7 +30,10 @@ if [ "$1" = "prof" ]; then
 $P --stats -d $E/prof_driver -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $E/bench_c2_driver_cmd_under_rocprof.json 2>/dev/null
 $P --stats -d $E/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-extras > $E/bench_c2_under_rocprof.json 2>/dev/null
 $P --stats -d $E/prof_c3 -- python3 $R/bench.py --workload C3 --steps 3356 --warmup 1678 --no-cpu-baseline --no-extras > /dev/null 2>&1
-MFCD_SKIP_TORCH=1 $P --stats -d $E/prof_uvt -- python3 $R/tools/bench_uvt.py C2 C3 C5 > /dev/null 2>&1
+MFCD_SKIP_TORCH=1 UVT_BENCH_SECONDS=0.04 $P --stats -d $E/prof_uvt -- python3 $R/tools/bench_uvt.py C2 C3 C5 > /dev/null 2>&1
+fi
+if [ "$1" = "profuvt" ]; then
+MFCD_SKIP_TORCH=1 UVT_BENCH_SECONDS=0.04 $P --stats -d $E/prof_uvt -- python3 $R/tools/bench_uvt.py C2 C3 C5 > /dev/null 2>&1
 fi
 if [ "$1" = "pmc" ]; then
 B="python3 $R/bench.py --no-cpu-baseline --no-extras --clock-ramp 0 --steps 2098 --warmup 1049"
