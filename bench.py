@@ -167,6 +167,7 @@ class Runner:
         # the workspace is planned ONCE for an epoch (as engine.fit does): no call of the run re-plans or re-initialises it
         engine.reserve_workspace(self.train.N, cfg["B"], cfg["n"], cfg["m"], cfg["d"], dev)
         self.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(64)]
+        self.loss_bufs = {}
 
     def _event(self):
         return self.event_pool.pop() if self.event_pool else torch.cuda.Event(enable_timing=True)
@@ -194,7 +195,10 @@ class Runner:
             if record:
                 e0, e1 = self._event(), self._event()
                 e0.record()
-            self.engine.train_steps(bind, self.stream[lo:hi], B, defer_step=True)
+            buf = self.loss_bufs.get(take)      # per call length, as a training loop keeps one per epoch
+            if buf is None:
+                buf = self.loss_bufs[take] = torch.empty(take, dtype=torch.float32, device=self.dev)
+            self.engine.train_steps(bind, self.stream[lo:hi], B, loss_out=buf, defer_step=True)
             if record:
                 e1.record()
                 self.train_events.append((e0, e1, take))

@@ -115,5 +115,10 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the handle without building a Stream object
+
+
 def stream_ptr(device=None):
+    if _raw_stream is not None and isinstance(device, torch.device) and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream

@@ -322,14 +322,14 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None,
     ptrs, n, m, d, dev, dtype = binding.call_context()
     N = samples_dev.shape[0]
     nsteps = (N + batch_size - 1) // batch_size
-    if loss_out is None:
-        loss_out = torch.empty(max(nsteps, 1), dtype=torch.float32, device=dev)
     if N == 0:
-        return loss_out[:0]
+        return torch.empty(0, dtype=torch.float32, device=dev) if loss_out is None else loss_out[:0]
+    if loss_out is None:
+        loss_out = torch.empty(nsteps, dtype=torch.float32, device=dev)
     ws = workspace_for(dev).ensure(N, batch_size, n, m, d, dev)
     lr, b1, b2, eps, wd = binding.hyper()
     args = ptrs + (_lib.ptr(samples_dev), N, batch_size, binding.step, n, m, d, lr, b1, b2, eps, wd,
-                   loss_out.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+                   loss_out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
     if dtype == torch.bfloat16:
         if kernel_us is not None:
             raise NotImplementedError("the timed diagnostic twin exists for fp32 factors only")
@@ -344,7 +344,7 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None,
         _lib.check(L.mfcd_train_steps_timed(*args, ctypes.cast(out, ctypes.c_void_p)))
         kernel_us[:] = [float(out[0]), float(out[1]), float(out[2])]
     binding.advance(nsteps, defer_step)
-    return loss_out[:nsteps]
+    return loss_out if loss_out.shape[0] == nsteps else loss_out[:nsteps]   # (a slice is ~1.6 us of host time)
 
 
 def eval_batches(U, V, samples_dev, batch_size, want_p=False):
