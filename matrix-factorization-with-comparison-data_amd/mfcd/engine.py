@@ -238,7 +238,7 @@ class Workspace:
         if self.buf is not None:
             _lib.check(_lib.load().mfcd_train_workspace_release(_lib.ptr(self.buf)))
             if keep_for_status:
-                self.retired.append(self.buf[:4])
+                self.retired.append(self.buf[:4].clone())   # stream-ordered copy of the word: the buffer itself is freed
         self.buf, self.plan, self.k_cap = None, None, 0
 
     def status(self):
@@ -248,23 +248,41 @@ class Workspace:
         return [int(w.view(torch.int32).item()) for w in words]
 
 
-_workspaces = {}   # (device index, stream handle) -> Workspace: one per device and stream, never shared between them
+_workspaces = {}   # (device index, stream handle, (n, m, d)) -> Workspace: one per device, stream and table shape, so
+                   # that two models of different shapes trained alternately do not re-plan each other's workspace
+_last_workspace = {}   # (device index, stream handle) -> the Workspace used last (diagnostics)
+_MAX_WORKSPACES_PER_STREAM = 6
 
 
-def workspace_for(device):
+def workspace_for(device, shape=None):
+    """The planned workspace of the current stream of `device` for tables of `shape` = (n, m, d); without a shape, the
+    one used last on that stream."""
     dev = device if isinstance(device, torch.device) else torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(dev).cuda_stream)
-    ws = _workspaces.get(key)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    base = (idx, _lib.stream_ptr(torch.device("cuda", idx)))
+    if shape is None:
+        ws = _last_workspace.get(base)
+        if ws is not None:
+            return ws
+        shape = ()
+    key = base + (tuple(shape),)
+    ws = _workspaces.pop(key, None)
     if ws is None:
-        ws = _workspaces[key] = Workspace()
+        ws = Workspace()
+        mine = [k for k in _workspaces if k[:2] == base]
+        for k in mine[:max(0, len(mine) - (_MAX_WORKSPACES_PER_STREAM - 1))]:   # least recently used first
+            old = _workspaces.pop(k)
+            old.drop(keep_for_status=True)
+            ws.retired += old.retired          # their status words are still looked at by check_status()
+    _workspaces[key] = ws                      # (re)inserted last = most recently used
+    _last_workspace[base] = ws
     return ws
 
 
 def reserve_workspace(n_samples, batch_size, n, m, d, device):
     """Plan the current stream's workspace for calls of up to `n_samples` samples (an epoch) BEFORE the first call, so
     that a short first call (warm-up, a partial epoch) does not size it too small and force a re-plan later."""
-    return workspace_for(device).ensure(n_samples, batch_size, n, m, d, torch.device(device))
+    return workspace_for(device, (n, m, d)).ensure(n_samples, batch_size, n, m, d, torch.device(device))
 
 
 TRAIN_PATHS = {"auto": 0, "streaming": 1, "resident": 2, "local": 3}
@@ -326,7 +344,7 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None,
         return torch.empty(0, dtype=torch.float32, device=dev) if loss_out is None else loss_out[:0]
     if loss_out is None:
         loss_out = torch.empty(nsteps, dtype=torch.float32, device=dev)
-    ws = workspace_for(dev).ensure(N, batch_size, n, m, d, dev)
+    ws = workspace_for(dev, (n, m, d)).ensure(N, batch_size, n, m, d, dev)
     lr, b1, b2, eps, wd = binding.hyper()
     args = ptrs + (_lib.ptr(samples_dev), N, batch_size, binding.step, n, m, d, lr, b1, b2, eps, wd,
                    loss_out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))

@@ -1312,3 +1312,45 @@ def test_uvt_column_split_knobs_change_the_grouping_not_the_result(dev, orc):
             engine.set_tuning(uvt_target_wgs=1)
     finally:
         engine.set_tuning(uvt_target_wgs=512, uvt_min_stages=8)
+
+
+@pytest.mark.gpu
+def test_models_of_different_shapes_keep_their_own_planned_workspaces(dev):
+    """Two models of different table shapes trained alternately on one stream: each keeps its planned workspace (no
+    re-plan per call), results equal training each alone; beyond six shapes per stream the least recently used
+    workspace is released and its sticky status word is still checked."""
+    from mfcd import engine
+    shapes = [(512, 384, 32), (300, 700, 16)]
+    data = []
+    for n, m, d in shapes:
+        U0, V0, u, i, j, z = _synthetic(n, m, d, 64 * 12 + 5, seed=n)
+        data.append((U0, V0, _records(u, i, j, z, n, m, dev)))
+
+    def alone(k):
+        model, opt = _model_from(data[k][0], data[k][1], dev, 1e-3, 1e-5)
+        bind = engine.AdamBinding(model, opt)
+        for _ in range(3):
+            engine.train_steps(bind, data[k][2].dev, 64)
+        return model.U.data.clone(), model.V.data.clone()
+
+    ref = [alone(0), alone(1)]
+    models = [_model_from(U0, V0, dev, 1e-3, 1e-5) for U0, V0, _ in data]
+    binds = [engine.AdamBinding(mo, op) for mo, op in models]
+    bufs = [None, None]
+    for rep in range(3):
+        for k in (0, 1):
+            engine.train_steps(binds[k], data[k][2].dev, 64)
+            ws = engine.workspace_for(dev, shapes[k])
+            if bufs[k] is None:
+                bufs[k] = ws.buf
+            assert ws.buf is bufs[k], "a model's workspace was re-planned by the other model's calls"
+    for k in (0, 1):
+        assert torch.equal(models[k][0].U.data, ref[k][0]) and torch.equal(models[k][0].V.data, ref[k][1])
+    for extra in range(7):                                   # more shapes than the per-stream cap: LRU release
+        n, m, d = 128 + 64 * extra, 128, 8
+        U0, V0, u, i, j, z = _synthetic(n, m, d, 64 * 3, seed=extra)
+        mo, op = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        engine.train_steps(engine.AdamBinding(mo, op), _records(u, i, j, z, n, m, dev).dev, 64)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    assert sum(1 for key in engine._workspaces if key[0] == idx) <= 6 * len({key[1] for key in engine._workspaces if key[0] == idx})
+    engine.check_status()
