@@ -384,7 +384,12 @@ def uvt_stats_sharded(U, V, X_rows, row0, s=1.0, what=3, group=None, slab_pass=h
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     spans = [(int(t[0]), int(t[1])) for t in metas]
-    if sorted(a for a, b in spans if b) != [a for a, b in spans if b] or sum(b for _, b in spans) != n:
+    at = 0
+    for a, b in spans:                      # rank order, contiguous, no overlap; a rank may hold no row
+        if b and a != at:
+            raise ValueError(f"row blocks must tile [0, {n}) in rank order, got {spans}")
+        at += b
+    if at != n:
         raise ValueError(f"row blocks must tile [0, {n}) in rank order, got {spans}")
     scal = None
     if what & 2:
