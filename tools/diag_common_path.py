@@ -15,6 +15,8 @@ if knobs:     # e.g. resident_q=4 resident_lookahead=8
 n = m = 4096; d = 64
 if size and size[0] == "C3":
     n = m = 16384; d = 128
+elif size and "x" in size[0]:      # e.g. 4096x32: n = m = 4096, d = 32
+    n = m = int(size[0].split("x")[0]); d = int(size[0].split("x")[1])
 for B, N in ((1, 20000), (8, 160000), (64, 67108)):
     model = S.MatrixFactorization(n, m, d).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
