@@ -176,6 +176,10 @@ void resident_train_kernel(ResidentArgs a)
             }
         }
     }
+#ifdef MFCD_TRACE
+    u64 dbg_t_arrive = 0;
+    int dbg_nhit = 0;
+#endif
 #ifdef MFCD_STAMPS
     [[maybe_unused]] u64 dbg_rt_age = 0, dbg_rt_n = 0;
     u64 dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -247,6 +251,9 @@ void resident_train_kernel(ResidentArgs a)
         }
         // rows owned by other waves: poll their granules until every tag is this step's
         unsigned spins = 0, limit = 0;
+#ifdef MFCD_TRACE
+        dbg_t_arrive = (u64)__builtin_amdgcn_s_memrealtime();
+#endif
         [[maybe_unused]] const u64 t_poll0 = STAMP();
         while (true) {
             bool ok = true;
@@ -290,6 +297,18 @@ void resident_train_kernel(ResidentArgs a)
             dbg_rt_age += now_rt - newest;                      // success time - (latest) publish time, 10 ns units
             dbg_rt_n += 1;
         }
+#ifdef MFCD_TRACE
+        // event trace (tools/trace_resident.py): one 32-byte record per hit behind the publish-time array:
+        // {sample position | own flags << 56, arrival (real-time clock, 10 ns), poll success, spins}
+        if (lane == 0 && dbg_nhit < 128) {
+            u64 *rec = a.mailbox + (int64_t)a.N * 3 * D + (int64_t)a.N * 3 + ((int64_t)gw * 128 + dbg_nhit) * 4;
+            rec[0] = (u64)pos | ((u64)(own[0] | (own[1] << 1) | (own[2] << 2)) << 56);
+            rec[1] = dbg_t_arrive;
+            rec[2] = (u64)__builtin_amdgcn_s_memrealtime();
+            rec[3] = spins;
+        }
+        dbg_nhit += 1;
+#endif
 #endif
         DBG_ADD(5, 1);
         DBG_ADD(6, spins);

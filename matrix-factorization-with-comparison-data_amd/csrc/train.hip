@@ -515,7 +515,7 @@ TrainLayout train_layout(int64_t N_cap, int B, int n, int m, int d)
         L.mailbox_off = b_off;
 #ifdef MFCD_STAMPS
         // diagnostic build: publish timestamps, one u64 per (sample, role), directly behind the mailbox
-        b_off += align256(L.mailbox_bytes + sizeof(unsigned long long) * (size_t)Nc * 3);
+        b_off += align256(L.mailbox_bytes + sizeof(unsigned long long) * (size_t)Nc * 3 + (size_t)4096 * 128 * 32);   // + hit trace
 #else
         b_off += align256(L.mailbox_bytes);
 #endif
@@ -660,6 +660,14 @@ extern "C" int mfcd_set_tuning(int key, int64_t value)
         default: return MFCD_EINVAL;
     }
 }
+
+#ifdef MFCD_STAMPS
+// diagnostic build only (tools/trace_resident.py): where the mailbox starts inside a workspace planned for these sizes
+extern "C" size_t mfcd_diag_mailbox_offset(int64_t N_cap, int B, int n, int m, int d)
+{
+    return train_layout(N_cap, B, n, m, d).mailbox_off;
+}
+#endif
 
 extern "C" size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d)
 {

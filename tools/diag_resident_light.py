@@ -41,3 +41,15 @@ for lo, hi in ((0, 35), (35, 45), (45, 55), (55, 65), (65, 200)):
     if sel.any():
         print(f"  waves with {lo:3d}-{hi:3d} hits: n={sel.sum():4d}  hit-block time {dbg[sel,3].mean()/tick_us:7.0f} us  publish {dbg[sel,4].mean()/tick_us:6.0f} us  "
               f"granule wait/hit {dbg[sel,1].sum()/dbg[sel,5].sum()/tick_us:.2f} us")
+# who sets the pace?  per-wave total granule wait: the waves that (almost) never wait are the critical ones
+wait_us = dbg[:, 1] / tick_us
+order_ = np.argsort(wait_us)
+pc = np.percentile(wait_us, [0, 1, 5, 25, 50, 75, 95, 100])
+print("per-wave total granule wait [us] percentiles 0/1/5/25/50/75/95/100: " + " ".join(f"{v:.0f}" for v in pc))
+print("the 12 waves that waited least (wave id, hits, publishes, wait us, hit-block non-wait us, publish us, common us):")
+for w in order_[:12]:
+    hb = dbg[w, 3] / tick_us
+    print(f"  wave {w:5d} (CU-slot {w // 16:4d}, XCD {(w // 4) % 8})  hits {h[w]:3d}  pubs {dbg[w,7]:3d}  wait {wait_us[w]:6.0f}  "
+          f"hit non-wait {hb - wait_us[w]:6.0f}  publish {dbg[w,4]/tick_us:5.0f}  common {(dbg[w,0]-dbg[w,3]-dbg[w,4])/tick_us:6.0f}")
+byx = [wait_us[((np.arange(len(wait_us)) // 4) % 8) == x].mean() for x in range(8)]
+print("mean wait by (workgroup id mod 8) = XCD: " + " ".join(f"{v:.0f}" for v in byx))
