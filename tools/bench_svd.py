@@ -1,3 +1,4 @@
+"""Diagnostic: singular values of X by Gram matrix + eigvalsh against torch.linalg.svdvals (time and agreement)."""
 import os, sys, time, torch
 sys.path[:0] = ["/root/repo", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "matrix-factorization-with-comparison-data_amd")]
 import generation_data as gd
