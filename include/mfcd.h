@@ -371,7 +371,7 @@ int mfcd_generate_labels(const int32_t *triplets, int64_t T, const float *X, int
 /*
  * Per-row Spearman rank correlation: rho[r] = Pearson correlation of the average ranks
  * (scipy.stats.rankdata semantics: ties share the mean of their positions; -0.0 ties with +0.0) of row r of A
- * [rows][lda] and row r of X [rows][ldx], m <= mfcd_spearman_max_columns() (16384) columns each.  Replaces the
+ * [rows][lda] and row r of X [rows][ldx], m <= mfcd_spearman_max_columns() (20448: BASELINE configs[4]'s 20000 fits) columns each.  Replaces the
  * reference's Python loop of scipy.stats.spearmanr over the rows of the centred U V^T and X (structure.py:1023-1031);
  * the caller forms the rows of U V^T with a plain library GEMM.  One workgroup per row: bitonic sort in LDS, exact
  * integer sums of the doubled centred ranks, rho in f64 (NaN for a constant row, as scipy).  Deterministic.

@@ -5,22 +5,24 @@
 // mean of their positions) of row r of A and row r of X.
 //
 // One workgroup of 1024 threads per row pair, everything in LDS:
-//   * the row becomes (sortable 32-bit key, 16-bit column) pairs, padded to a power of two P <= 16384 with keys that
-//     sort last; -0.0 ranks as +0.0 (numeric equality, as numpy compares);
-//   * bitonic sort of the pairs (P/2 compare-exchanges per stage, log2(P)(log2(P)+1)/2 stages, one barrier each);
+//   * the row becomes (sortable 32-bit key, 16-bit column) pairs; -0.0 ranks as +0.0 (numeric equality, as numpy
+//     compares);
+//   * bitonic sort of the pairs in the normalised (all-ascending) form over the next power of two P, the positions past
+//     m being virtual keys that sort last and never move (P/2 comparators per stage, log2(P)(log2(P)+1)/2 stages, one
+//     barrier each);
 //   * every run of equal keys gets the doubled average rank 2*rank = first + last + 2 (0-based positions), written by
 //     the thread that holds the run's first element;
 //   * A's doubled ranks are scattered back to column order (u16); during X's pass each sorted element looks up its
 //     column's A rank, and the three sums of the correlation are accumulated as EXACT 64-bit integers of the doubled,
 //     centred ranks (|2 rank - (m+1)| <= m, sums <= 4 m^3 < 2^46), reduced in fixed order; rho is formed in f64.
 // The result is therefore independent of thread scheduling and equals scipy's float64 computation to rounding.
-// LDS: 6 P + 2 m bytes (128 KiB at m = 16384).  Rows longer than 16384 are not handled here (host: torch ops).
+// LDS: 8 m bytes (156 KiB at m = 20000).  Rows longer than 20448 are not handled here (host: torch ops).
 #include "common.h"
 
 namespace {
 
 constexpr int kRankThreads = 1024;
-constexpr int kRankMaxCols = 16384;
+constexpr int kRankMaxCols = 20448;   // 8 bytes of LDS per column (+ the reduction scratch) within 160 KiB
 
 __device__ __forceinline__ unsigned sortable_key(float f)
 {
@@ -46,9 +48,9 @@ __global__ __launch_bounds__(kRankThreads) void spearman_rows_kernel(const float
                                                                      int P, double *__restrict__ rho)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned *key = reinterpret_cast<unsigned *>(smem);                       // [P]
-    unsigned short *idx = reinterpret_cast<unsigned short *>(key + P);         // [P]
-    unsigned short *ra2 = idx + P;                                             // [m] doubled rank of A by column
+    unsigned *key = reinterpret_cast<unsigned *>(smem);                       // [m]
+    unsigned short *idx = reinterpret_cast<unsigned short *>(key + m);         // [m]
+    unsigned short *ra2 = idx + m;                                             // [m] doubled rank of A by column
     __shared__ long long red[kRankThreads / 64];
     const int tid = threadIdx.x;
     const int64_t r = blockIdx.x;
@@ -57,17 +59,24 @@ __global__ __launch_bounds__(kRankThreads) void spearman_rows_kernel(const float
 
     for (int pass = 0; pass < 2; ++pass) {
         const float *row = pass == 0 ? A + r * lda : X + r * ldx;
-        for (int p = tid; p < P; p += kRankThreads) {
-            key[p] = p < m ? sortable_key(row[p]) : 0xFFFFFFFFu;
+        for (int p = tid; p < m; p += kRankThreads) {
+            key[p] = sortable_key(row[p]);
             idx[p] = (unsigned short)p;
         }
         __syncthreads();
+        // Bitonic network over P = next power of two, in its NORMALISED form: every comparator is ascending (the first
+        // step of a merge pairs an element with its mirror image in the block, the following steps are half-cleaners).
+        // Positions m .. P-1 are VIRTUAL keys that sort last: with ascending comparators only they never move, so a
+        // comparator that touches one is a no-op and is skipped, and LDS holds m elements, not P (m = 20000, BASELINE
+        // configs[4], fits: 8 m bytes).
         for (int k = 2; k <= P; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int t = tid; t < (P >> 1); t += kRankThreads) {
-                    const int i = 2 * j * (t / j) + (t % j), l = i + j;
+                    const int i = 2 * j * (t / j) + (t % j);
+                    const int l = (j == (k >> 1)) ? (i ^ (k - 1)) : i + j;   // mirror in the k-block / half-cleaner
+                    if (l >= m) continue;
                     const unsigned a = key[i], b = key[l];
-                    if ((a > b) == ((i & k) == 0)) {
+                    if (a > b) {
                         key[i] = b;
                         key[l] = a;
                         const unsigned short ia = idx[i];
@@ -78,8 +87,7 @@ __global__ __launch_bounds__(kRankThreads) void spearman_rows_kernel(const float
                 __syncthreads();
             }
         }
-        // NaN keys (sortable value above +inf's) and the padding sort last; a padded key can only tie with a real
-        // 0xFFFFFFFF key, which no finite float or infinity produces
+        // NaN keys (sortable value above +inf's) sort last among the real ones
         long long s_own = 0, s_xy = 0;
         for (int p = tid; p < m; p += kRankThreads) {
             const unsigned kp = key[p];
@@ -114,7 +122,7 @@ extern "C" int mfcd_spearman_rows(const float *A, int64_t lda, const float *X, i
     if (rows == 0) return 0;
     int P = 2;
     while (P < m) P <<= 1;
-    const size_t lds = (size_t)P * 6 + (size_t)m * 2;
+    const size_t lds = (size_t)m * 8;
     static size_t allowed = 0;
     if (lds > allowed) {
         MFCD_HIP_TRY(hipFuncSetAttribute((const void *)spearman_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

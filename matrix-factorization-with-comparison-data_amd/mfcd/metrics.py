@@ -124,7 +124,7 @@ def _rank_rows(M):
 
 def spearman_rows(A, X):
     """Per-row Spearman rho of two [rows, m] fp32 GPU matrices (rows may be strided views) → f64 [rows] on device.
-    HIP kernel (include/mfcd.h: mfcd_spearman_rows), m <= 16384."""
+    HIP kernel (include/mfcd.h: mfcd_spearman_rows), m <= mfcd_spearman_max_columns() = 20448."""
     L = _lib.load()
     rows, m = A.shape
     if X.shape != A.shape or A.dtype != torch.float32 or X.dtype != torch.float32 or not A.is_cuda or not X.is_cuda:
@@ -161,7 +161,7 @@ def _x_singular_values(X, xmean):
 
 def spearman_and_svd(U, V, X_centred_rows_mean, X, alpha, ok_rows, row_block=2048):
     """per-row Spearman rho (HIP rank kernel on rows of U V^T formed by a plain library GEMM; torch
-    sort-based ranks only for rows longer than the kernel's 16384 columns) and the singular-value error."""
+    sort-based ranks only for rows longer than the kernel's 20448 columns) and the singular-value error."""
     n, m = X.shape
     rho = torch.empty(n, dtype=torch.float64, device=X.device)
     vbar = V.mean(dim=0, keepdim=True)

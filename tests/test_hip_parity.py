@@ -873,7 +873,8 @@ def test_zipf_head_stream_through_every_form(dev, orc, form):
 # --------------------------------------------------------------------------------------------------
 # (f) SURVEY 8f N4: Spearman rank kernel
 # --------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("rows,m", [(64, 5), (33, 100), (64, 1000), (48, 3001), (256, 4096), (24, 16384), (3, 2)])
+@pytest.mark.parametrize("rows,m", [(64, 5), (33, 100), (64, 1000), (48, 3001), (256, 4096), (24, 16384), (3, 2), (12, 16385),
+                                    (16, 20000), (8, 20448)])   # 20000 = BASELINE configs[4]; 20448 = the kernel's limit
 def test_spearman_rows_match_scipy(dev, rows, m):
     """mfcd_spearman_rows against scipy's own spearmanr, row by row (the reference's call, structure.py:1028), and the
     oracle's vectorised restatement: continuous rows, heavily tied rows (five distinct values, as ratings), rows with
