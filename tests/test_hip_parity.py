@@ -1355,3 +1355,42 @@ def test_models_of_different_shapes_keep_their_own_planned_workspaces(dev):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     assert sum(1 for key in engine._workspaces if key[0] == idx) <= 6 * len({key[1] for key in engine._workspaces if key[0] == idx})
     engine.check_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rank-d", "rank-d + noise", "full rank, flat spectrum"])
+def test_singular_value_error_from_the_top_of_the_spectrum_equals_the_dense_solver(dev, kind):
+    """svd_error_scaled (structure.py:1011-1017) needs only the min(d, n, m) largest singular values of the centred X and
+    its Frobenius norm (the rest of UV^T's spectrum is zero).  The block-iteration path must agree with the dense
+    eigen-solver path to 1e-9 where it accepts its result, and hand over to the dense path where the spectrum does not
+    let it converge."""
+    from mfcd import metrics
+    n, m, d = 700, 900, 16
+    g = torch.Generator().manual_seed(5)
+    A, Bm = torch.randn(n, d, generator=g), torch.randn(m, d, generator=g)
+    X = (A @ Bm.t()) / d ** 0.5
+    if kind == "rank-d + noise":
+        X = X + 0.05 * torch.randn(n, m, generator=g)
+    if kind == "full rank, flat spectrum":
+        X = torch.randn(n, m, generator=g)
+    X = X.to(dev).contiguous()
+    U = (torch.randn(n, d, generator=g) / d ** 0.5).to(dev)
+    V = (torch.randn(m, d, generator=g) / d ** 0.5).to(dev)
+    xm = X.mean(1)
+    ok = np.ones(n, dtype=bool)
+    metrics._x_top_cache.clear(); metrics._x_spectrum_cache.clear()
+    _, fast, failed = metrics.spearman_and_svd(U, V, xm, X, 0.7, ok)
+    took_fast = any(v is not None for v in metrics._x_top_cache.values())
+    assert not failed
+    real = metrics._x_top_spectrum
+    metrics._x_top_spectrum = lambda *a, **k: None          # force the dense path
+    try:
+        _, dense, failed2 = metrics.spearman_and_svd(U, V, xm, X, 0.7, ok)
+    finally:
+        metrics._x_top_spectrum = real
+    assert not failed2
+    assert fast == pytest.approx(dense, rel=1e-9, abs=1e-12)
+    if kind == "rank-d":
+        assert took_fast, "a rank-d matrix must converge in the block iteration"
+    if kind == "full rank, flat spectrum":
+        assert not took_fast, "a flat spectrum must be handed to the dense solver"

@@ -9,11 +9,19 @@ n, m, d = 100000, 20000, 256
 g = torch.Generator(device=dev).manual_seed(1)
 U = torch.randn(n, d, device=dev, generator=g) / d ** 0.5
 V = torch.randn(m, d, device=dev, generator=g) / d ** 0.5
-X = torch.empty(n, m, device=dev)
-for r0 in range(0, n, 8192):
-    X[r0:r0 + 8192].normal_(0.0, 0.5, generator=g)
-X += 0.3 * (U @ V.t())
+kind = sys.argv[1] if len(sys.argv) > 1 else "rank-d"
+if kind == "rank-d":       # what the reference's generators produce: X = A B^T with d columns (entries of std 0.5)
+    A = torch.randn(n, d, device=dev, generator=g)
+    Bf = torch.randn(m, d, device=dev, generator=g)
+    X = (A @ Bf.t()) * (0.5 / d ** 0.5)
+    del A, Bf
+else:                      # full rank with a flat spectrum: the block iteration hands over to the dense solver
+    X = torch.empty(n, m, device=dev)
+    for r0 in range(0, n, 8192):
+        X[r0:r0 + 8192].normal_(0.0, 0.5, generator=g)
+    X += 0.3 * (U @ V.t())
 torch.cuda.synchronize()
+print(f"X: {kind}")
 for rep in range(2):
     t0 = time.perf_counter(); e = metrics.reconstruction_error(U, V, X, 1.0); torch.cuda.synchronize(); t1 = time.perf_counter()
     out = metrics.alpha_and_norm_ratios(U, V, X); torch.cuda.synchronize(); t2 = time.perf_counter()
