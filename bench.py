@@ -23,6 +23,7 @@ for _p in (ROOT, PKG):
         sys.path.insert(0, _p)
 
 os.environ.setdefault("OMP_NUM_THREADS", "4")  # the reference's own setting (structure.py:3)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # CPU baseline: idle OpenMP threads sleep instead of spinning on a shared box
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -91,6 +92,27 @@ def algorithmic_valu_cycles_per_step(cfg):
     return regs * (ADAM_FAST_PLAIN * CYC_PLAIN + ADAM_FAST_TRANS * CYC_TRANS)
 
 
+def offline_traffic(cfg, plan, abytes):
+    """`traffic_offline`: the newest committed counter measurement of this kernel (profiles/r*_pmc_traffic.json, made by
+    tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the guide's gfx950
+    correction).  No counter pass can run inside this process, so `traffic` itself stays null; this names the file the
+    figure comes from and its ratio to the algorithmic bytes."""
+    import glob
+    if cfg.get("name", "C2") != "C2" or plan["form_name"] != "resident":
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rec = json.load(f)
+        b = float(rec["hbm_bytes_per_step"])
+        return {"file": os.path.relpath(files[-1], ROOT), "bytes_per_step": int(b),
+                "ratio_to_algorithmic": round(b / abytes, 4), "kernel_config": rec.get("config")}
+    except Exception:
+        return None
+
+
 def roofline_record(cfg, plan, period_us, kernel_us=None, kernel_step_us=None):
     """`roofline` object for the form that actually ran (engine.train_plan), per optimiser step.
     Streaming form: HBM-bound, achieved = algorithmic bytes / time.  Resident / local forms: the state never leaves
@@ -130,6 +152,7 @@ def roofline_record(cfg, plan, period_us, kernel_us=None, kernel_step_us=None):
                "traffic_note": "null: no counter pass ran inside this process; offline rocprofv3 --pmc figures for this "
                                "kernel are under profiles/ (README there names the file per round)",
                "kernel": kern}
+    rec["traffic_offline"] = offline_traffic(cfg, plan, abytes)
     rec["priced_on"] = ("dominant kernel's launch duration / steps per launch (HIP event pair around the launch)"
                         if kernel_step_us else "whole call period (HIP event pair around the call)")
     rec["launch_period_us"] = round(call_period_us, 3)
@@ -224,6 +247,43 @@ class Runner:
         return out
 
 
+def host_cpu_share():
+    """(usable cores, how that was found, CPU model string).  A container sees every hardware thread of the host in its
+    affinity mask but is scheduled on a cgroup CPU quota (the GPU box: 256 threads visible, 16 cores' worth of quota);
+    OpenMP teams larger than the quota only add contention (round 2's "all cores" figure was 262 updates/s at 256
+    threads against 330 k at 16), so the baseline's "all host cores" run uses min(affinity, quota)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota, how = None, "sched_getaffinity"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(float(q) / float(per) + 0.5))
+    except Exception:
+        try:                                                           # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                quota = max(1, int(q / per + 0.5))
+        except Exception:
+            pass
+    cores = aff
+    if quota is not None and quota < aff:
+        cores, how = quota, "cgroup cpu quota"
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return cores, how, aff, model
+
+
 def cpu_baseline(cfg, seed, budget_s=12.0):
     """The CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload."""
     import shutil
@@ -239,16 +299,19 @@ def cpu_baseline(cfg, seed, budget_s=12.0):
         except Exception:
             lib = O.build()
         orc = O.COracle(lib)
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncpu, share_from, visible, cpu_model = host_cpu_share()
         results = {}
-        for threads in sorted({1, min(ncpu, 16), ncpu}):   # 1 thread, 16 threads, ALL host cores
+        # 1 thread, the reference's own 4 (structure.py:3), 16, and ALL usable host cores (the cgroup share when the box
+        # exposes more hardware threads than it schedules; a box without a quota reports its affinity mask, capped at 64
+        # threads: the sweep is 0.5 M elements per step and does not scale past that)
+        for threads in sorted({1, min(ncpu, 4), min(ncpu, 16), min(ncpu, 64)}):
             st = O.new_state(U0, V0)
             probe = tr[: 32 * B]
             t0 = time.perf_counter()
             orc.train_steps(st, probe[:, 0], probe[:, 1], probe[:, 2], probe[:, 3], B, 0, lr=cfg["lr"], wd=cfg["wd"],
                             threads=threads)
             per = (time.perf_counter() - t0) / 32
-            nsteps = int(max(64, min(200000, (budget_s / 3) / max(per, 1e-6))))
+            nsteps = int(max(64, min(200000, (budget_s / 4) / max(per, 1e-6))))
             reps = (nsteps * B + len(tr) - 1) // len(tr)
             sample = np.tile(tr, (reps, 1))[: nsteps * B]   # several epochs' worth of the same workload
             t0 = time.perf_counter()
@@ -274,11 +337,14 @@ def cpu_baseline(cfg, seed, budget_s=12.0):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     v, nsteps, dt = results[best]
+    allc = min(ncpu, 64)
     return {"value": round(v, 1), "unit": "triplet-updates/s", "cores": int(best), "kind": "port",
             "sample": f"{nsteps} optimiser steps (B={B}) of the {cfg.get('name', 'C2')} workload in {dt:.1f}s, C oracle "
-                      f"(oracle/mfcd_oracle.c, -O3 -march=native, OpenMP Adam sweep); host has {ncpu} usable cores",
+                      f"(oracle/mfcd_oracle.c, -O3 -march=native, OpenMP Adam sweep, passive wait policy); host has "
+                      f"{ncpu} usable cores ({share_from}; {visible} hardware threads visible)",
+            "cpu_model": cpu_model,
             "by_threads": {str(k): round(r[0], 1) for k, r in results.items()},
-            "all_cores": {"cores": int(ncpu), "value": round(results[ncpu][0], 1)},
+            "all_cores": {"cores": int(allc), "value": round(results[allc][0], 1), "from": share_from},
             "torch_op_port_4thr": round(tp, 1),
             "reference_vs_port": "profiles/r02_reference_vs_port_cpu.txt (build container: the unmodified reference's "
                                  "step time beside this port's, same data)"}
@@ -301,7 +367,7 @@ class _StdoutToStderr:
         return False
 
 
-def clock_ramp(runner, seconds):
+def clock_ramp(runner, seconds, call_steps=20):
     """UNTIMED, in front of the warm-up steps and the timed region: keep the chip busy for `seconds` with the same fused-step calls on a SCRATCH
     copy of the model (the measured model and its optimiser are not touched).  A GPU that has sat idle while the host
     prepared the inputs answers its first launches at idle clocks and wake-up latency (measured on this pool: the first
@@ -320,7 +386,7 @@ def clock_ramp(runner, seconds):
     while time.perf_counter() - t0 < seconds:
         for _ in range(16):
             runner.pos = 0
-            runner.run(20, record=True, bind=bind)
+            runner.run(call_steps, record=True, bind=bind)
         calls += 16
         torch.cuda.synchronize()
         runner.event_pool.extend(e for a, b, _ in runner.train_events for e in (a, b))
@@ -328,7 +394,9 @@ def clock_ramp(runner, seconds):
     runner.stream, runner.pos, runner.pre.pending = saved[0], saved[1], saved[2]
     runner.gen.set_state(saved[3])
     return {"untimed": True, "seconds": round(time.perf_counter() - t0, 3), "calls": calls,
-            "what": "20-step fused calls on a scratch copy of the model, directly in front of the warm-up steps and the timed region"}
+            "call_steps": call_steps,
+            "what": f"{call_steps}-step fused calls (the timed region's call length) on a scratch copy of the model, directly "
+                    "in front of the warm-up steps and the timed region"}
 
 
 def uvt_record(dev, U2, V2):
@@ -495,7 +563,7 @@ def _run(args):
     # front of the timed one: the first launch after the ramp's bursts of queued calls pays ~9 us of runtime housekeeping on
     # the host (tools/exp_driver_first.py), which is not part of a step
     runner.open_epoch()
-    ramp = clock_ramp(runner, args.clock_ramp) if args.clock_ramp > 0 else None
+    ramp = clock_ramp(runner, args.clock_ramp, max(1, min(args.steps, runner.steps_per_epoch))) if args.clock_ramp > 0 else None
     runner.run(args.warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -10,6 +10,7 @@
 //   * bitonic sort of the pairs in the normalised (all-ascending) form over the next power of two P, the positions past
 //     m being virtual keys that sort last and never move (P/2 comparators per stage, log2(P)(log2(P)+1)/2 stages, one
 //     barrier each);
+//   * a NaN anywhere in either row makes rho NaN (scipy's nan_policy='propagate');
 //   * every run of equal keys gets the doubled average rank 2*rank = first + last + 2 (0-based positions), written by
 //     the thread that holds the run's first element;
 //   * A's doubled ranks are scattered back to column order (u16); during X's pass each sorted element looks up its
@@ -56,11 +57,14 @@ __global__ __launch_bounds__(kRankThreads) void spearman_rows_kernel(const float
     const int64_t r = blockIdx.x;
     const long long centre = (long long)m + 1;     // 2 * mean rank
     long long saa = 0, sxx = 0, sxy = 0;
+    int has_nan = 0;   // scipy.stats.spearmanr propagates NaN: a NaN anywhere in either row makes rho NaN
 
     for (int pass = 0; pass < 2; ++pass) {
         const float *row = pass == 0 ? A + r * lda : X + r * ldx;
         for (int p = tid; p < m; p += kRankThreads) {
-            key[p] = sortable_key(row[p]);
+            const float f = row[p];
+            has_nan |= (f != f);
+            key[p] = sortable_key(f);
             idx[p] = (unsigned short)p;
         }
         __syncthreads();
@@ -107,7 +111,9 @@ __global__ __launch_bounds__(kRankThreads) void spearman_rows_kernel(const float
         __syncthreads();                                         // ra2 complete / key, idx free for the next pass
     }
     const long long Saa = block_sum_i64(saa, red), Sxx = block_sum_i64(sxx, red), Sxy = block_sum_i64(sxy, red);
-    if (tid == 0) rho[r] = (double)Sxy / (sqrt((double)Saa) * sqrt((double)Sxx));   // 0/0 -> NaN, as scipy for constants
+    has_nan = __syncthreads_or(has_nan);
+    if (tid == 0)   // 0/0 -> NaN, as scipy for constants
+        rho[r] = has_nan ? __longlong_as_double(0x7ff8000000000000ll) : (double)Sxy / (sqrt((double)Saa) * sqrt((double)Sxx));
 }
 
 }  // namespace

@@ -463,6 +463,7 @@ constexpr unsigned kMaxLaunchId = (1u << (32 - kTagStepBits)) - 1;
 struct TrainLayout {
     size_t dbg_off, stage_off, stage_bytes, terms_off, touch_off, touch_bytes;
     size_t ualt_off, valt_off, xs_off, mailbox_off, mailbox_bytes, total;
+    size_t alt_end;  // end of the streaming members of the union (U_alt, V_alt)
     int64_t K_cap;
     bool resident;   // the resident regions exist
 };
@@ -520,6 +521,7 @@ TrainLayout train_layout(int64_t N_cap, int B, int n, int m, int d)
         b_off += align256(L.mailbox_bytes);
 #endif
     }
+    L.alt_end = a_off;
     L.total = a_off > b_off ? a_off : b_off;
     return L;
 }
@@ -550,6 +552,9 @@ struct WsState {
     int B = 0, n = 0, m = 0, d = 0;
     TrainLayout L{};
     unsigned launch_id = 0;    // resident launches so far (mod kMaxLaunchId): the tag base of the next one
+    bool mailbox_dirty = false;   // a streaming-form call wrote U_alt / V_alt over the head of the mailbox (same union):
+                                  // fp32 bit patterns there could pass for tagged granules, so the next resident launch
+                                  // zeroes that prefix first
     StageSlot slot[kStageSlots];
     unsigned next = 0;
     ~WsState()
@@ -802,6 +807,13 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
                 S->launch_id = 0;
             }
             tag_base = ++S->launch_id << kTagStepBits;
+            if (S->mailbox_dirty) {
+                if (L.alt_end > L.mailbox_off) {
+                    const size_t nb = L.alt_end - L.mailbox_off;
+                    MFCD_HIP_TRY(hipMemsetAsync(mailbox, 0, nb < L.mailbox_bytes ? nb : L.mailbox_bytes, st));
+                }
+                S->mailbox_dirty = false;
+            }
         }
         const int rpw = resident ? 64 * fc.rp.Q / d : 0;
         const int want_touch = resident && fc.rp.lookahead > 0;
@@ -847,6 +859,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     }
 
     // ---- streaming form: one launch per optimiser step ----
+    if (L.resident) S->mailbox_dirty = true;
     TP *Ualt = (TP *)(base + L.ualt_off);
     TP *Valt = (TP *)(base + L.valt_off);
     float *terms = (float *)(base + L.terms_off);

@@ -386,6 +386,18 @@ def dense_grad_from_coefficients(U, V, samples_dev, g):
     """Dense [n,d], [m,d] fp32 gradients of a scalar loss w.r.t. U, V from g[t] = dLoss/dx_t (include/mfcd.h:
     mfcd_dense_grad_from_coefficients) — the backward of the forward kernel for ANY loss on its output."""
     L = _lib.load()
+    _require_cuda_param(U, "U", _FACTOR_DTYPES)
+    _require_cuda_param(V, "V", _FACTOR_DTYPES)
+    if U.dtype != V.dtype:
+        raise ValueError("U and V must share the storage dtype")
+    if U.dtype != torch.float32:
+        # the scatter kernel is fp32-only: widen exactly, accumulate in fp32, hand back gradients of the tables' dtype
+        # (running the fp32 kernel over bf16 storage would read and write twice the tables' size)
+        gU, gV = dense_grad_from_coefficients(U.float(), V.float(), samples_dev, g)
+        return gU.to(U.dtype), gV.to(V.dtype)
+    g = g.to(dtype=torch.float32).contiguous()
+    if g.numel() != samples_dev.shape[0]:
+        raise ValueError("one coefficient per sample record is needed")
     (n, d), m = U.shape, V.shape[0]
     gU, gV = torch.empty_like(U), torch.empty_like(V)
     _lib.check(L.mfcd_dense_grad_from_coefficients(_lib.ptr(U), _lib.ptr(V), _lib.ptr(samples_dev), _lib.ptr(g),
@@ -495,19 +507,21 @@ def fit(model, train_loader, val_loader, optimizer, num_epochs, progress=None):
     # this epoch's step kernel is enqueued, i.e. underneath it.
     pre = StreamPrefetch(dev)
     bs = None
-    if num_epochs > 0:
-        order, bs = epoch_order(train_loader)           # structure.py:845 iter(train_loader)
-        pre.start(train, order)
-    for e in it:
-        stream = pre.take()
-        per_epoch_train.append(train_steps(binding, stream, bs, defer_step=True))
-        vorder, vbs = epoch_order(val_loader)           # structure.py:861 iter(val_loader)
-        if e + 1 < num_epochs:
-            order, bs = epoch_order(train_loader)       # next epoch's structure.py:845
+    try:
+        if num_epochs > 0:
+            order, bs = epoch_order(train_loader)           # structure.py:845 iter(train_loader)
             pre.start(train, order)
-        vl, _, _ = eval_batches(U, V, val.ordered(vorder), vbs)
-        per_epoch_val.append(vl)
-    binding.flush()
+        for e in it:
+            stream = pre.take()
+            per_epoch_train.append(train_steps(binding, stream, bs, defer_step=True))
+            vorder, vbs = epoch_order(val_loader)           # structure.py:861 iter(val_loader)
+            if e + 1 < num_epochs:
+                order, bs = epoch_order(train_loader)       # next epoch's structure.py:845
+                pre.start(train, order)
+            vl, _, _ = eval_batches(U, V, val.ordered(vorder), vbs)
+            per_epoch_val.append(vl)
+    finally:
+        binding.flush()     # an interrupt must not leave the moments ahead of the optimizer's `step` tensors
     # one device->host transfer for the whole run (the reference syncs every step at 852); the status word is
     # sticky, so an abort in ANY epoch surfaces here
     check_status()

@@ -9,6 +9,8 @@ Spearman correlations (structure.py:1023-1031) run on the HI
 library GEMM.  The singular-value error (structure.py:1011-1017) stays on torch's dense eigen-solver: U V^T
 has rank <= d, so its spectrum comes from a d x d problem, and X's spectrum is cached per X.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -122,6 +124,28 @@ def _rank_rows(M):
     return ranks
 
 
+def spearman_rows_sorted(A, X):
+    """Per-row Spearman rho for rows LONGER than the LDS kernel holds (m > mfcd_spearman_max_columns(), e.g. BASELINE
+    configs[3]'s 65536 items): device sort, run-averaged ranks, f64 sums.  NaN in either row -> NaN (scipy propagates)."""
+    ra, rx = _rank_rows(A), _rank_rows(X)
+    ra = ra - ra.mean(1, keepdim=True)
+    rx = rx - rx.mean(1, keepdim=True)
+    rho = (ra * rx).sum(1) / torch.sqrt((ra * ra).sum(1) * (rx * rx).sum(1))
+    bad = torch.isnan(A).any(1) | torch.isnan(X).any(1)
+    return torch.where(bad, torch.full_like(rho, float("nan")), rho)
+
+
+def spearman_rows_any(A, X, row_block=1024):
+    """Per-row Spearman rho for any row length: the HIP rank kernel up to its column limit, the device sort path above it
+    (in row blocks: its temporaries are ~40 bytes per element)."""
+    if A.shape[1] <= _lib.load().mfcd_spearman_max_columns():
+        return spearman_rows(A, X)
+    out = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
+    for r0 in range(0, A.shape[0], row_block):
+        out[r0:r0 + row_block] = spearman_rows_sorted(A[r0:r0 + row_block], X[r0:r0 + row_block])
+    return out
+
+
 def spearman_rows(A, X):
     """Per-row Spearman rho of two [rows, m] fp32 GPU matrices (rows may be strided views) → f64 [rows] on device.
     HIP kernel (include/mfcd.h: mfcd_spearman_rows), m <= mfcd_spearman_max_columns() = 20448."""
@@ -138,28 +162,46 @@ def spearman_rows(A, X):
     return rho
 
 
-_x_spectrum_cache = {}
+class _PerMatrixCache:
+    """One entry, tied to the tensor OBJECT it was computed for: a weak reference that must still resolve to the very
+    same tensor, plus its in-place version counter and the caller's extra key.  (Keys made of data_ptr/shape alone go
+    stale: the caching allocator hands a freed X's block to the next X of the same shape — ADVICE r2.)"""
+
+    def __init__(self):
+        self._ref, self._key, self._val = None, None, None
+
+    def clear(self):
+        self._ref, self._key, self._val = None, None, None
+
+    def get(self, X, extra=()):
+        if self._ref is not None and self._ref() is X and self._key == (X._version, X.data_ptr(), extra):
+            return True, self._val
+        return False, None
+
+    def put(self, X, val, extra=()):
+        self._ref, self._key, self._val = weakref.ref(X), (X._version, X.data_ptr(), extra), val
+
+
+_x_spectrum_cache = _PerMatrixCache()
 
 
 def _x_singular_values(X, xmean):
     """Singular values of the row-centred X from the Gram matrix on its smaller side (f64): same spectrum as
     torch.linalg.svd(X) to ~4e-8 relative at C2 and 40x cheaper than svdvals (118 ms vs 4.6 s at 4096^2).
     X is constant while a model trains and is evaluated against it, so the spectrum is cached per X (keyed by
-    storage address, shape and in-place version counter)."""
-    key = (X.data_ptr(), tuple(X.shape), X._version, str(X.device))
-    hit = _x_spectrum_cache.get(key)
-    if hit is not None:
+    tensor object and in-place version counter)."""
+    found, hit = _x_spectrum_cache.get(X)
+    if found:
         return hit
     n, m = X.shape
     Xc = (X - xmean[:, None]).double()
     G = Xc @ Xc.t() if n <= m else Xc.t() @ Xc
     s1 = torch.sqrt(torch.clamp(torch.linalg.eigvalsh(G), min=0.0)).flip(0)
-    _x_spectrum_cache.clear()            # one X at a time
-    _x_spectrum_cache[key] = s1
+    _x_spectrum_cache.put(X, s1)         # one X at a time
     return s1
 
 
-_x_top_cache = {}
+_x_top_cache = _PerMatrixCache()
 
 
 def _x_top_spectrum(X, xmean, r, tol=1e-11, max_iter=40, oversample=16):
@@ -176,9 +218,9 @@ def _x_top_spectrum(X, xmean, r, tol=1e-11, max_iter=40, oversample=16):
     b = r + oversample
     if r <= 0 or 2 * b > dim:
         return None
-    key = (X.data_ptr(), tuple(X.shape), X._version, str(X.device), r)
-    if key in _x_top_cache:
-        return _x_top_cache[key]                # (None is cached too: a spectrum that did not converge is not retried)
+    found, hit = _x_top_cache.get(X, r)
+    if found:
+        return hit                              # (None is cached too: a spectrum that did not converge is not retried)
     Xc = (X - xmean[:, None]).double()
     fro2 = float((Xc * Xc).sum())
     if n <= m:
@@ -204,8 +246,7 @@ def _x_top_spectrum(X, xmean, r, tol=1e-11, max_iter=40, oversample=16):
             break                                               # not contracting: leave it to the dense solver
         prev_res = rel
         Q = torch.linalg.qr(Z).Q
-    _x_top_cache.clear()                        # one X at a time
-    _x_top_cache[key] = out
+    _x_top_cache.put(X, out, r)                 # one X at a time
     return out
 
 
@@ -220,13 +261,7 @@ def spearman_and_svd(U, V, X_centred_rows_mean, X, alpha, ok_rows, row_block=204
     for r0 in range(0, n, row_block):
         r1 = min(n, r0 + row_block)
         A = U[r0:r1] @ Vc.t()                              # row-centred UV^T block (ranks ignore the shift)
-        if in_kernel:
-            rho[r0:r1] = spearman_rows(A, X[r0:r1])
-            continue
-        ra, rx = _rank_rows(A), _rank_rows(X[r0:r1])
-        ra = ra - ra.mean(1, keepdim=True)
-        rx = rx - rx.mean(1, keepdim=True)
-        rho[r0:r1] = (ra * rx).sum(1) / torch.sqrt((ra * ra).sum(1) * (rx * rx).sum(1))
+        rho[r0:r1] = spearman_rows(A, X[r0:r1]) if in_kernel else spearman_rows_any(A, X[r0:r1])
     rho = rho.cpu().numpy()
     scores = [np.float64(r) for r, o in zip(rho, ok_rows) if o and not np.isnan(r)]  # spearmanr yields np.float64
     # singular values: X centred (n x m); UV^T centred has rank <= d -> spectrum from a d x d problem

@@ -421,13 +421,16 @@ def test_data_parallel_hip_backend_single_rank(dev, mode):
     np.testing.assert_allclose(model.V.data.cpu().numpy(), ref_V, rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("world,N", [(1, 64 * 9 + 5), (2, 64 * 2 * 7 + 70), (3, 64 * 3 * 5 + 130), (8, 64 * 8 * 3 + 1)])
-def test_native_dp_loop_single_process_rehearsal(dev, world, N):
+@pytest.mark.parametrize("world,N,shape", [(1, 64 * 9 + 5, None), (2, 64 * 2 * 7 + 70, None), (3, 64 * 3 * 5 + 130, None),
+                                           (8, 64 * 8 * 3 + 1, None), (8, 64 * 8 * 4 + 77, (65536, 65536, 64))])
+def test_native_dp_loop_single_process_rehearsal(dev, world, N, shape):
     """mfcd_dp_train_steps without a communicator computes every rank's shard in this process (replicas are
     identical, so that IS the gathered buffer): shard bounds, padding of short / empty shards and the global divisor
-    must make the run bit-identical to the fused streaming step with batch_size = 64 * world."""
+    must make the run bit-identical to the fused streaming step with batch_size = 64 * world.  Last case: world 8 at
+    BASELINE configs[3] (C4) table shape, the configuration the data-parallel form is named for."""
     from mfcd import dist as mdist, engine
-    n, m, d, B = 300, 260, 32, 64
+    n, m, d, B = shape or (300, 260, 32), 64
+    n, m, d = n
     U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=100 + world)
     st = _records(u, i, j, z, n, m, dev)
     engine.set_train_path("streaming")
@@ -978,8 +981,9 @@ def test_device_label_generation_follows_the_btl_law(dev):
 # --------------------------------------------------------------------------------------------------
 # (h) VERDICT r1 item 5: row-sharded state, batch 64 (strong scaling), results equal to one GPU
 # --------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("world", [1, 2, 3, 8])
-@pytest.mark.parametrize("n,m,d,N", [(300, 200, 64, 64 * 40 + 7), (37, 29, 5, 64 * 12 + 1), (5, 3, 16, 64 * 6)])
+@pytest.mark.parametrize("world,n,m,d,N", [(w, *shp) for w in (1, 2, 3, 8) for shp in
+                                           ((300, 200, 64, 64 * 40 + 7), (37, 29, 5, 64 * 12 + 1), (5, 3, 16, 64 * 6))] +
+                         [(8, 65536, 65536, 64, 64 * 6 + 5)])       # world 8 at BASELINE configs[3] (C4) table shape
 def test_row_sharded_rehearsal_is_bit_identical_to_the_streaming_step(dev, world, n, m, d, N):
     """mfcd_shard_train_steps without a communicator plays every rank in this process (pack of the owned rows ->
     union of the packs = what the integer all-reduce yields -> fused step per shard, in place).  With the batch kept at
@@ -1380,7 +1384,7 @@ def test_singular_value_error_from_the_top_of_the_spectrum_equals_the_dense_solv
     ok = np.ones(n, dtype=bool)
     metrics._x_top_cache.clear(); metrics._x_spectrum_cache.clear()
     _, fast, failed = metrics.spearman_and_svd(U, V, xm, X, 0.7, ok)
-    took_fast = any(v is not None for v in metrics._x_top_cache.values())
+    took_fast = metrics._x_top_cache._val is not None
     assert not failed
     real = metrics._x_top_spectrum
     metrics._x_top_spectrum = lambda *a, **k: None          # force the dense path
@@ -1394,3 +1398,170 @@ def test_singular_value_error_from_the_top_of_the_spectrum_equals_the_dense_solv
         assert took_fast, "a rank-d matrix must converge in the block iteration"
     if kind == "full rank, flat spectrum":
         assert not took_fast, "a flat spectrum must be handed to the dense solver"
+
+
+# --------------------------------------------------------------------------------------------------
+# round 3: parity holes named by the round-2 review
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rank-d", "rank-d + noise"])
+def test_alpha_and_norm_ratios_at_2048_squared_match_the_oracle(dev, kind):
+    """compute_alpha_and_norm_ratios (structure.py:958-1082) at 2048 x 2048, d = 64 against the oracle's restatement
+    (numpy SVDs of the centred matrices, scipy ranks): all 14 outputs at the north-star bound 1e-4 (scaled by the
+    magnitude of the reference value), in particular svd_err, which the product path takes from a block iteration on
+    the top of X's spectrum.  Fixture sizes (<= 256^2) could not tell a wrong tail term from a right one."""
+    import structure as S
+    from oracle import oracle as O
+    n = m = 2048
+    d = 64
+    g = torch.Generator().manual_seed(77 if kind == "rank-d" else 78)
+    A, Bm = torch.randn(n, d, generator=g), torch.randn(m, d, generator=g)
+    X = (A @ Bm.t()) / (2.0 * d ** 0.5)
+    if kind == "rank-d + noise":
+        X = X + 0.05 * torch.randn(n, m, generator=g)
+    U0 = (0.6 * A / d ** 0.25 + 0.3 * torch.randn(n, d, generator=g) / d ** 0.5).numpy().astype(np.float32)
+    V0 = (0.6 * Bm / d ** 0.25 + 0.3 * torch.randn(m, d, generator=g) / d ** 0.5).numpy().astype(np.float32)
+    model, _ = _model_from(U0, V0, dev, 1e-3, 0.0)
+    Xd = X.to(dev).contiguous()
+    res = S.compute_alpha_and_norm_ratios(model, Xd)
+    ref = O.alpha_and_norm_ratios(U0, V0, X.numpy())
+    names = ["alpha", "norm_X", "norm_ratio", "rec_scaled", "pearson_mean", "pearson_std", "spearman_mean",
+             "spearman_std", "svd_err", "slopes", "correlations", "spearman_scores", "rec_scaled_per_row",
+             "alpha_per_row"]
+    assert len(res) == len(ref) == 14
+    for nm, v, r in zip(names, res, ref):
+        v, r = np.asarray(v, dtype=np.float64), np.asarray(r, dtype=np.float64)
+        assert v.shape == r.shape, nm
+        scale = max(1.0, float(np.max(np.abs(r))) if r.size else 1.0)
+        np.testing.assert_allclose(v, r, rtol=0, atol=1e-4 * scale, err_msg=nm)
+    assert 0.0 < res[8] < 1.0 and res[8] != 1.0          # the SVD branch ran (1.0 is the swallowed-failure value)
+
+
+@pytest.mark.gpu
+def test_x_spectrum_cache_is_tied_to_the_matrix_not_to_its_address(dev):
+    """same-shape ground truths created one after the other (run_experiment's repetitions) tend to get the
+    same device block back from the caching allocator; the spectrum cache must not hand X_1's singular values to X_2.
+    Each svd_err is compared with the dense route on a fresh cache."""
+    from mfcd import metrics
+    n, m, d = 512, 384, 16
+    g = torch.Generator().manual_seed(5)
+    U = (torch.randn(n, d, generator=g) / d ** 0.5).to(dev)
+    V = (torch.randn(m, d, generator=g) / d ** 0.5).to(dev)
+    ok = np.ones(n, dtype=bool)
+    seen_ptrs, got, want = [], [], []
+    for rep in range(4):
+        X = ((torch.randn(n, d, generator=g) @ torch.randn(d, m, generator=g)) * (0.2 + 0.1 * rep)).to(dev).contiguous()
+        seen_ptrs.append(X.data_ptr())
+        xm = X.mean(1)
+        _, e_fast, failed = metrics.spearman_and_svd(U, V, xm, X, 0.8, ok)
+        assert not failed
+        got.append(e_fast)
+        Xc = (X - xm[:, None]).double()
+        s1 = torch.linalg.svdvals(Xc)
+        Vc = (V - V.mean(0, keepdim=True)).double()
+        s2 = torch.linalg.svdvals(U.double() @ Vc.t())
+        k = min(len(s1), len(s2))
+        want.append(float(torch.linalg.norm(0.8 * s2[:k] - s1[:k]) / (torch.linalg.norm(s1[:k]) + 1e-8)))
+        del X, Xc
+    assert len(set(seen_ptrs)) < len(seen_ptrs), "the allocator did not reuse a block: the test did not test anything"
+    np.testing.assert_allclose(got, want, rtol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,m", [(6, 20449), (5, 32768), (4, 65536)])    # 65536 = BASELINE configs[3]'s item count
+def test_spearman_rows_longer_than_the_lds_kernel_match_scipy(dev, rows, m):
+    """Rows longer than mfcd_spearman_max_columns() (20448) take the device sort path of mfcd.metrics (torch.sort +
+    run-averaged ranks, f64 sums).  Same checks as the kernel's test: scipy.stats.spearmanr row by row, ties in one and
+    in both operands, -0.0 / +0.0, a constant row (NaN), a NaN entry (NaN, as scipy)."""
+    from scipy.stats import spearmanr
+    from mfcd import metrics
+    rng = np.random.default_rng(m)
+    A = rng.standard_normal((rows, m)).astype(np.float32)
+    X = (0.6 * A + rng.standard_normal((rows, m))).astype(np.float32)
+    X[1] = np.round(X[1] * 2.0) / 2.0
+    A[2], X[2] = rng.integers(0, 5, m).astype(np.float32), rng.integers(0, 5, m).astype(np.float32)
+    A[0, : m // 2] = 0.0
+    A[0, 0] = -0.0
+    X[3] = 1.25
+    got = metrics.spearman_rows_any(torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev)).cpu().numpy()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = np.array([spearmanr(A[r], X[r]).correlation for r in range(rows)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, equal_nan=True)
+    assert np.isnan(got[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [1000, 20000, 30000])
+def test_spearman_of_a_row_with_nan_is_nan_as_scipy(dev, m):
+    """scipy.stats.spearmanr returns NaN when either operand holds a NaN (nan_policy='propagate'); both
+    device paths (LDS kernel, long-row sort path) must do the same instead of ranking NaN as the largest value."""
+    from mfcd import metrics
+    rng = np.random.default_rng(m)
+    A = rng.standard_normal((4, m)).astype(np.float32)
+    X = rng.standard_normal((4, m)).astype(np.float32)
+    A[1, m // 3] = np.nan
+    X[2, m - 1] = np.nan
+    got = metrics.spearman_rows_any(torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev)).cpu().numpy()
+    assert np.isfinite(got[0]) and np.isfinite(got[3])
+    assert np.isnan(got[1]) and np.isnan(got[2])
+
+
+@pytest.mark.gpu
+def test_bf16_tables_with_a_generic_optimiser_are_refused_or_widened_never_overrun(dev):
+    """the dense-gradient kernel is fp32-only.  bf16 factor tables must never reach it as raw pointers
+    (it would read and write twice the tables' size): the autograd route widens exactly and returns bf16 gradients
+    that match the fp32 computation on the widened tables; fit_generic refuses bf16 up front."""
+    import structure as S
+    from mfcd import engine, _lib
+    n, m, d, N = 50, 40, 16, 100
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=3)
+    rec = _records(u, i, j, z, n, m, dev).dev
+    Ub = torch.from_numpy(U0).to(dev).bfloat16()
+    Vb = torch.from_numpy(V0).to(dev).bfloat16()
+    g = torch.linspace(-1, 1, N, device=dev)
+    guard = torch.full((n * d,), 7.0, device=dev)           # sits near the outputs in the allocator's pool
+    gU, gV = engine.dense_grad_from_coefficients(Ub, Vb, rec, g)
+    assert gU.dtype == torch.bfloat16 and gU.shape == Ub.shape and gV.shape == Vb.shape
+    rU, rV = engine.dense_grad_from_coefficients(Ub.float(), Vb.float(), rec, g)
+    assert torch.equal(gU, rU.bfloat16()) and torch.equal(gV, rV.bfloat16())
+    assert bool((guard == 7.0).all())
+    model = S.MatrixFactorization(n, m, d, dtype=torch.bfloat16).to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    rows = np.stack([u, i, j, z], 1)
+    mk = lambda r: torch.utils.data.DataLoader(ListDataset(r), batch_size=64, shuffle=False)  # noqa: E731
+    with pytest.raises(_lib.MfcdError):
+        engine.fit_generic(model, mk(rows), mk(rows[:10]), opt, 1)
+
+
+@pytest.mark.gpu
+def test_row_block_sharded_uvt_pass_rehearsal_at_c5_shape(dev, orc):
+    """SURVEY 8e G1 at BASELINE configs[4] (C5: 100000 x 20000, d = 256): the eight row blocks an 8-rank run would
+    hold, each through mfcd_uvt_stats_slab, shares added in rank order, against the one-pass result (fp32-rounding
+    level: per-tile sums group by each slab's own column split) and against the oracle on 128 sampled rows."""
+    from mfcd import dist as mdist, metrics
+    n, m, d, world = 100000, 20000, 256, 8
+    g = torch.Generator(device=dev).manual_seed(4242)
+    U = torch.randn(n, d, device=dev, generator=g) / d ** 0.5
+    V = torch.randn(m, d, device=dev, generator=g) / d ** 0.5
+    X = torch.empty(n, m, device=dev)
+    for r0 in range(0, n, 8192):
+        X[r0:r0 + 8192].normal_(0.1, 0.5, generator=g)
+    rs_d, sc_d = metrics.uvt_stats(U, V, X, 0.9)
+    cuts = [n * r // world for r in range(world + 1)]
+    blocks, scal = [], torch.zeros(4, dtype=torch.float64, device=dev)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        rs, share = mdist.hip_slab_pass(U, V, X[lo:hi], lo, 0.9, 3)
+        blocks.append(rs)
+        scal += share
+    rs_s = torch.cat(blocks)
+    for col in range(6):
+        scale = float(rs_d[:, col].abs().max()) + 1e-30
+        assert float((rs_s[:, col] - rs_d[:, col]).abs().max()) <= 2e-5 * scale, col
+    np.testing.assert_allclose(scal[:2].cpu().numpy(), sc_d[:2].cpu().numpy(), rtol=2e-6)
+    rows = torch.randperm(n, generator=torch.Generator().manual_seed(8))[:128].sort().values.to(dev)
+    ref_rows, _, _ = orc.uvt_stats(U[rows].cpu().numpy(), V.cpu().numpy(), X[rows].cpu().numpy(), 0.9)
+    got = rs_s[rows].cpu().numpy()
+    np.testing.assert_allclose(got[:, 1], ref_rows[:, 1], rtol=2e-5)
+    np.testing.assert_allclose(got[:, 2], ref_rows[:, 2], rtol=2e-5)
