@@ -23,7 +23,6 @@ for _p in (ROOT, PKG):
         sys.path.insert(0, _p)
 
 os.environ.setdefault("OMP_NUM_THREADS", "4")  # the reference's own setting (structure.py:3)
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # CPU baseline: idle OpenMP threads sleep instead of spinning on a shared box
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -340,7 +339,7 @@ def cpu_baseline(cfg, seed, budget_s=12.0):
     allc = min(ncpu, 64)
     return {"value": round(v, 1), "unit": "triplet-updates/s", "cores": int(best), "kind": "port",
             "sample": f"{nsteps} optimiser steps (B={B}) of the {cfg.get('name', 'C2')} workload in {dt:.1f}s, C oracle "
-                      f"(oracle/mfcd_oracle.c, -O3 -march=native, OpenMP Adam sweep, passive wait policy); host has "
+                      f"(oracle/mfcd_oracle.c, -O3 -march=native, OpenMP Adam sweep); host has "
                       f"{ncpu} usable cores ({share_from}; {visible} hardware threads visible)",
             "cpu_model": cpu_model,
             "by_threads": {str(k): round(r[0], 1) for k, r in results.items()},

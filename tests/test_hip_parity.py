@@ -429,8 +429,7 @@ def test_native_dp_loop_single_process_rehearsal(dev, world, N, shape):
     must make the run bit-identical to the fused streaming step with batch_size = 64 * world.  Last case: world 8 at
     BASELINE configs[3] (C4) table shape, the configuration the data-parallel form is named for."""
     from mfcd import dist as mdist, engine
-    n, m, d, B = shape or (300, 260, 32), 64
-    n, m, d = n
+    (n, m, d), B = shape or (300, 260, 32), 64
     U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=100 + world)
     st = _records(u, i, j, z, n, m, dev)
     engine.set_train_path("streaming")
