@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MFCD_ABI_VERSION 2
+#define MFCD_ABI_VERSION 3
 
 #define MFCD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, d out of range)   */
 #define MFCD_EWORKSPACE (-2) /* workspace smaller than mfcd_*_workspace_bytes says             */
@@ -201,6 +201,23 @@ int mfcd_train_steps_timed(float *U, float *V, float *mU, float *vU, float *mV, 
                            int d, double lr, double beta1, double beta2, double eps, double weight_decay,
                            float *loss_per_step, void *workspace, size_t workspace_bytes, void *stream,
                            float *kernel_us_host);
+
+/*
+ * Prepared calls: everything about a training call that does not change from call to call — the six table pointers,
+ * the table shape and dtype, the batch size, the Adam hyper-parameters and the planned workspace — bound ONCE into a
+ * handle, so that the per-call boundary is five scalars (round-2 review: a 20-step call spent ~24 us of its ~50 us in
+ * argument marshalling on the host side of the boundary).  mfcd_train_call_run(handle, ...) is mfcd_train_steps /
+ * mfcd_train_steps_bf16 with the bound arguments: same forms, same results, same stream semantics.  The handle borrows
+ * the pointers (nothing is copied or owned); release it before the tables, the moments or the workspace go away, and
+ * prepare a new one when any bound value changes (a learning-rate schedule, a re-planned workspace).
+ * Replaces, on the reference side, the per-epoch body of train_model (structure.py:845-852).
+ */
+int mfcd_train_call_prepare(void *U, void *V, float *mU, float *vU, float *mV, float *vV, int bf16_factors, int B,
+                            int n, int m, int d, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, void *workspace, size_t workspace_bytes, void **handle_out);
+int mfcd_train_call_run(void *handle, const mfcd_sample *samples, int64_t N, int64_t step0, float *loss_per_step,
+                        void *stream);
+int mfcd_train_call_release(void *handle);
 
 /*
  * Split form for data-parallel training (one exchange step between the two calls):

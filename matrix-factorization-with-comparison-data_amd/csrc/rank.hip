@@ -111,9 +111,9 @@ __global__ __launch_bounds__(kRankThreads) void spearman_rows_kernel(const float
         __syncthreads();                                         // ra2 complete / key, idx free for the next pass
     }
     const long long Saa = block_sum_i64(saa, red), Sxx = block_sum_i64(sxx, red), Sxy = block_sum_i64(sxy, red);
-    has_nan = __syncthreads_or(has_nan);
+    const long long Snan = block_sum_i64((long long)has_nan, red);   // (not __syncthreads_or: it takes LDS of its own)
     if (tid == 0)   // 0/0 -> NaN, as scipy for constants
-        rho[r] = has_nan ? __longlong_as_double(0x7ff8000000000000ll) : (double)Sxy / (sqrt((double)Saa) * sqrt((double)Sxx));
+        rho[r] = Snan != 0 ? __longlong_as_double(0x7ff8000000000000ll) : (double)Sxy / (sqrt((double)Saa) * sqrt((double)Sxx));
 }
 
 }  // namespace

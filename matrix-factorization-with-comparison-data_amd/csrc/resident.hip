@@ -112,7 +112,41 @@ static int resident_blocks_per_cu(int d, int Q, int look, int fast, int bf16, in
 // is 16 for Q <= 2 (4 workgroups of 4 waves hide each other's hand-off latency: +7 % at C2 over 2 per CU) and 8 above;
 // whether the code object really admits that many is asked of the runtime (resident_blocks_per_cu) and the plan is
 // refused otherwise, so that a compiler that allocates more registers ends in the streaming form, not in a spin.
-ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, bool bf16)
+// smallest slice (registers per array) whose wave count the chip can hold: geometry only (no tuning knob, no occupancy
+// query), the same rule the plan applies first
+static int resident_default_q(int n, int m, int d, int num_cus)
+{
+    if (d < 2 || d > 256 || (d & (d - 1)) != 0 || num_cus <= 0) return 0;
+    const int64_t T = (int64_t)(n + m) * d;
+    static const int kQ[5] = {1, 2, 4, 16, 32};
+    for (int Q : kQ) {
+        if ((64 * Q) % d != 0) continue;
+        const int64_t nw = (T + 64 * (int64_t)Q - 1) / (64 * Q);
+        if (nw <= (int64_t)num_cus * (Q <= 2 ? 16 : 8) && nw <= kResidentMaxWaves) return Q;
+    }
+    return 0;
+}
+
+ResidentEvents resident_events(int B, int n, int m, int d, int num_cus)
+{
+    ResidentEvents ev{0, 0, 0};
+    const int Q = resident_default_q(n, m, d, num_cus);
+    if (!Q || B > 64) return ev;
+    ev.rows_per_wave = 64 * Q / d;
+    ev.waves = (int)(((int64_t)(n + m) * d + 64 * (int64_t)Q - 1) / (64 * Q));
+    // expected list entries per wave and step for uniformly drawn rows; a chunk of T steps (plus the boundary copies of
+    // the deepest window) should average <= 20 of the 64 slots, so that an overflow is a property of the data (a row
+    // most batches name), not of chance: P[Poisson(20) > 64] ~ 1e-14
+    const double h = 3.0 * B * ev.rows_per_wave / (double)(n + m);
+    for (int ts = 8; ts >= 4; --ts)
+        if (h * ((1 << ts) + kResidentEventLook) <= 20.0) {
+            ev.tshift = ts;
+            break;
+        }
+    return ev;
+}
+
+ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, bool bf16, int ev_tshift)
 {
     ResidentPlan pl{};
     pl.ok = false;
@@ -123,6 +157,8 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, b
     int look = resident_lookahead(N, B, n, m);
     const bool fast = g_resident_math != 0;
     if (bf16 && look >= 8) look = 4;
+    if (ev_tshift < 0) ev_tshift = resident_events(B, n, m, d, num_cus).tshift;
+    if (ev_tshift == 0) look = 0;          // no event lists for this shape: publish right before use
     static const int kQ[5] = {1, 2, 4, 16, 32};
     for (int qi = 0; qi < 5; ++qi) {
         const int Q = kQ[qi];
@@ -140,6 +176,7 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, b
             pl.lookahead = look;
             pl.fast_math = fast;
             pl.bf16 = bf16;
+            pl.tshift = ev_tshift;
             return pl;
         }
     }
@@ -150,10 +187,11 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, b
 //  (a) copies the call's host-built table (ResidentCold + per-step Adam scalars) into the workspace: out of the
 //      kernel-argument segment for calls of up to 223 steps, else from the pinned staging slot, which the kernel reads
 //      directly over the host link (no separate H2D copy on the stream either way);
-//  (b) resident form only: translates the call's samples to VIRTUAL row ids (xs) and builds the touch strings:
-//      touch[string][k >> 5] bit (k & 31) = batch k holds a sample with a row of that string (one string per wave,
-//      or per virtual row for waves of up to 4 rows: the kernel's ROWWIN).  The strings are all-zero on entry
-//      (workspace init + every wave clears its own strings at the end of a launch).
+//  (b) resident form only: translates the call's samples to VIRTUAL row ids (xs) and, for the look-ahead form, appends
+//      every sample to the event list of each wave that owns one of its rows (resident_kernel.h: list (wave, chunk of
+//      2^tshift steps); the first `look` steps of a chunk are also copied into the previous chunk's list).  The list
+//      counters are all-zero on entry (workspace init + every wave clears its own counters at the end of a launch);
+//      an entry that finds its list full is dropped and the count says so (the wave then takes the generic loop).
 // INLINE: the table travels in the kernel-argument segment itself (first parameter, so it sits at offset 0 of the
 // segment, which every lane can address); short calls then need no read over the host link at all.
 constexpr int kInlineStageUnits = 232;   // 16-byte units: ResidentCold (8) + 224 step scalars; 3712 bytes of kernarg
@@ -161,12 +199,20 @@ struct InlineStage {
     uint4 v[kInlineStageUnits];
 };
 
+__device__ __forceinline__ void event_append(unsigned *__restrict__ ev_cnt, uint4 *__restrict__ ev_ent, size_t list,
+                                             const uint4 &e)
+{
+    const unsigned slot = atomicAdd(ev_cnt + list, 1u);
+    if (slot < (unsigned)kEventCap) ev_ent[list * kEventCap + slot] = e;
+}
+
 template <bool INLINE>
 __global__ __launch_bounds__(256) void train_prologue_kernel(InlineStage inl, const uint4 *__restrict__ stage_host,
                                                              uint4 *__restrict__ stage_dev, int stage_units,
                                                              const mfcd_sample *__restrict__ samples, int64_t N, int B,
-                                                             int n, int m, int rows_per_wave, int KW, int want_touch,
-                                                             mfcd_sample *__restrict__ xs, unsigned *__restrict__ touch)
+                                                             int n, int m, int rows_per_wave, int tshift, int look,
+                                                             int64_t nch_cap, mfcd_sample *__restrict__ xs,
+                                                             unsigned *__restrict__ ev_cnt, uint4 *__restrict__ ev_ent)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < stage_units) {
@@ -184,27 +230,37 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(InlineStage inl, co
     s.i = rm.vrow_v(s.i);
     s.j = rm.vrow_v(s.j);
     xs[t] = s;
-    if (!want_touch) return;
+    if (look <= 0) return;
     const int k = (int)(t / B);
-    const unsigned bit = 1u << (k & 31);
-    const int word = k >> 5;
-    const int gr = rows_per_wave <= 4 ? 1 : rows_per_wave;
-    const int wu = s.u / gr, wi = s.i / gr, wj = s.j / gr;
-    atomicOr(touch + (size_t)wu * KW + word, bit);
-    if (wi != wu) atomicOr(touch + (size_t)wi * KW + word, bit);
-    if (wj != wi && wj != wu) atomicOr(touch + (size_t)wj * KW + word, bit);
-}
-
-int resident_touch_words(int64_t K) { return (int)((K + 31) / 32 + 3); }
-
-size_t resident_touch_bytes(int64_t K)
-{
-    return sizeof(unsigned) * (size_t)(4 * kResidentMaxWaves + 4) * (size_t)resident_touch_words(K);   // <= 4 rows/wave
+    const unsigned tl = (unsigned)(t - (int64_t)k * B);
+    const int w[3] = {s.u / rows_per_wave, s.i / rows_per_wave, s.j / rows_per_wave};
+    const unsigned lr[3] = {(unsigned)(s.u - w[0] * rows_per_wave), (unsigned)(s.i - w[1] * rows_per_wave),
+                            (unsigned)(s.j - w[2] * rows_per_wave)};
+    const int c = k >> tshift;
+    const bool copy_back = c > 0 && (k & ((1 << tshift) - 1)) < look;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        bool first = true;                     // one entry per distinct owner wave of the sample
+#pragma unroll
+        for (int r2 = 0; r2 < r; ++r2) first = first && w[r2] != w[r];
+        if (!first) continue;
+        unsigned own = 0u, rows = 0u;
+#pragma unroll
+        for (int r2 = r; r2 < 3; ++r2)
+            if (w[r2] == w[r]) {
+                own |= 1u << r2;
+                rows |= lr[r2] << (10 * r2);
+            }
+        const uint4 e = make_uint4(((unsigned)k << 9) | (tl << 3) | own, rows, __float_as_uint(s.z), 0u);
+        const size_t list = (size_t)w[r] * (size_t)nch_cap + (size_t)c;
+        event_append(ev_cnt, ev_ent, list, e);
+        if (copy_back) event_append(ev_cnt, ev_ent, list - 1, e);
+    }
 }
 
 int launch_train_prologue(const void *stage_host, const void *stage_host_devview, void *stage_dev, size_t stage_bytes,
-                          const mfcd_sample *samples, int64_t N, int B, int n, int m, int rows_per_wave, int KW,
-                          int want_touch, mfcd_sample *xs, unsigned *touch, hipStream_t st)
+                          const mfcd_sample *samples, int64_t N, int B, int n, int m, int rows_per_wave, int tshift,
+                          int look, int64_t nch_cap, mfcd_sample *xs, unsigned *ev_cnt, void *ev_ent, hipStream_t st)
 {
     const int units = (int)((stage_bytes + 15) / 16);
     const int64_t items = xs ? (N > units ? N : units) : units;
@@ -213,11 +269,13 @@ int launch_train_prologue(const void *stage_host, const void *stage_host_devview
         InlineStage inl;
         std::memcpy(inl.v, stage_host, (size_t)units * 16);
         hipLaunchKernelGGL(train_prologue_kernel<true>, grid, dim3(256), 0, st, inl, (const uint4 *)nullptr,
-                           (uint4 *)stage_dev, units, samples, N, B, n, m, rows_per_wave, KW, want_touch, xs, touch);
+                           (uint4 *)stage_dev, units, samples, N, B, n, m, rows_per_wave, tshift, look, nch_cap, xs,
+                           ev_cnt, (uint4 *)ev_ent);
     } else {
         static const InlineStage none{};
         hipLaunchKernelGGL(train_prologue_kernel<false>, grid, dim3(256), 0, st, none, (const uint4 *)stage_host_devview,
-                           (uint4 *)stage_dev, units, samples, N, B, n, m, rows_per_wave, KW, want_touch, xs, touch);
+                           (uint4 *)stage_dev, units, samples, N, B, n, m, rows_per_wave, tshift, look, nch_cap, xs,
+                           ev_cnt, (uint4 *)ev_ent);
     }
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
@@ -225,7 +283,7 @@ int launch_train_prologue(const void *stage_host, const void *stage_host_devview
 
 int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev, const mfcd_sample *xs, int64_t N, int B, int n,
                           int m, int d, const StepScalars *sc_dev, const AdamStatic &ac, unsigned long long *mailbox,
-                          unsigned tag_base, float *loss_terms, unsigned long long *dbg, int K, hipStream_t st)
+                          unsigned tag_base, void *loss_terms, unsigned long long *dbg, int K, hipStream_t st)
 {
     ResidentArgs a;
     a.dbg = dbg;

@@ -58,40 +58,48 @@ __host__ __device__ inline RowMap make_row_map(int n, int m)
     return r;
 }
 
-// Diagnostic build (-DMFCD_STAMPS, tools/ only): per-wave cycle accounting written to a debug region.
-// dbg[gw*8 + {0 total, 1 poll-wait, 2 hit-compute, 3 adam, 4 publish, 5 hits, 6 polls, 7 hit-steps}]
-#ifdef MFCD_STAMPS
-#define STAMP() ((u64)__builtin_amdgcn_s_memtime())
-#define DBG_ADD(slot, val) dbg_acc[slot] += (val)
-// MFCD_STAMPS=2 ("light"): no stamp on the common path — slot 3 = whole hit block of a step (record load .. last hit),
-// slot 4 = publish slow path only, slot 7 = number of publish slow paths — so that the step loop keeps its timing
-#else
-#define STAMP() ((u64)0)
-#define DBG_ADD(slot, val) ((void)0)
-#endif
+// ---- per-wave event lists (look-ahead form) ----
+// The prologue kernel of a call hands every owner wave the list of the samples that name one of its rows, cut into
+// CHUNKS of T = 2^tshift optimiser steps: list (wave w, chunk c) holds one 16-byte entry per such sample of steps
+// [cT, (c+1)T), plus a copy of the entries of the first LOOK steps of chunk c + 1 (the look-ahead window reaches across
+// the boundary), at most kEventCap of them, in arrival order of the prologue's atomics.  The wave loads a chunk's list
+// into ONE entry per lane, sorts it by (step, slot in the batch) and from then on decides everything — is there a hit at
+// this step, which row is due for publishing and into which mailbox slot, which granules to request a step ahead — with
+// ballots and v_readlane on three registers: no record load sits in front of a hit or a publish any more (round 2: two
+// dependent memory round trips per hit), and the per-step path of a wave without events is one scalar compare.
+//   word 0: step k << 9 | slot in the batch << 3 | own-role mask (bit r: the sample's role r = u, i, j is a row of mine)
+//   word 1: my local row index of role 0 | role 1 << 10 | role 2 << 20   (valid where the own bit is set)
+//   word 2: the sample's label z (fp32 bits);  word 3: unused
+// A list that does not fit (a row that most batches name: popularity-sampled heads) makes its wave take the generic
+// publish-right-before-use loop for the whole launch; the granule protocol is the same, so the two kinds of wave mix.
+constexpr int kEventCap = 64;
+constexpr unsigned kEventNone = 0xFFFFFFF8u;   // sorts last, step 0x7FFFFF, no own role
+constexpr int kEventMaxLocalRows = 1024;
 
-// Pointers needed only when the slice is loaded at kernel start and stored at kernel end.  They live in device
-// memory (workspace) and are (re)read with scalar loads at those two points, so they do not occupy SGPRs during
-// the step loop (with them passed by value the kernel needed > 102 SGPRs and spilled scalars into VGPR lanes on
-// every step).
+// Pointers needed only at a few points of a launch.  They live in device memory (workspace) and are (re)read with
+// scalar loads there, so they do not occupy SGPRs during the step loop (with them passed by value the kernel needed
+// > 102 SGPRs and spilled scalars into VGPR lanes on every step).
 struct ResidentCold {
     float *U, *V, *mU, *vU, *mV, *vV;
     int *status;                     // 0 = ok, 1 = a bounded spin expired (sticky: never cleared by a launch)
     unsigned long long spin_limit;   // polls before a wave gives up
-    unsigned *touch;                 // [strings][KW]: bit s of a string = "batch s touches a row of that string" (look-
-                                     // ahead form); all-zero between launches: every wave clears its own strings
-    long long KW;                    // dwords per string (covers K + 64 steps; bits past K are zero)
-    unsigned long long pad[6];       // 128 bytes
+    unsigned *ev_cnt;                // [waves][nch_cap] entries appended to list (wave, chunk); all-zero between launches
+                                     // (every wave clears its own counters at the end of a launch)
+    uint4 *ev_ent;                   // [waves][nch_cap][kEventCap] entries
+    long long nch_cap;               // chunks per wave the two arrays are laid out for
+    long long tshift;                // log2(steps per chunk)
+    float *loss_out;                 // [K] batch-mean BCE per step, formed inside the launch (look-ahead form); may be null
+    unsigned long long pad[3];       // 128 bytes
 };
 static_assert(sizeof(ResidentCold) == 128, "train.hip fills this block as sixteen 8-byte words (kColdBytes)");
 
 struct ResidentArgs {
     const ResidentCold *cold;
     const mfcd_sample *samples;   // the call's samples with u, i, j already translated to VIRTUAL row ids
-    const StepScalars *sc;   // [K]
+    const StepScalars *sc;   // [K + 1]
     u64 *mailbox;            // [N][3][D] granules; a granule is valid when its tag == tag_base + step + 1
-    float *loss_terms;       // [N]
-    u64 *dbg;                // [NW][8] cycle accounting (diagnostic build only)
+    void *loss_terms;        // look-ahead form: u64 [N] granules {tag, sigmoid output}; generic form: float [N] sigmoid outputs
+    u64 *dbg;                // [8] who gave up first (diagnostics): {wave, step, sample position, own mask}
     unsigned tag_base;       // launch id << 21 (train.hip): granules left behind by earlier launches never match
     int64_t N;
     int B, n, m, K, NW;
@@ -139,6 +147,7 @@ void resident_train_kernel(ResidentArgs a)
     constexpr int RPR = D < 64 ? 64 / D : 1;   // rows per register when D < 64
     constexpr int EW = 64 * Q;
     static_assert(EW % D == 0, "a wave's slice must hold whole rows");
+    static_assert(EW / D <= kEventMaxLocalRows, "local row indices are 10-bit fields of an event entry");
     constexpr bool GRL = Q >= 16;             // row-gradient accumulators in LDS
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];   // [4 waves][64*Q] when GRL (+ the lds_pad knob)
     const int lane = threadIdx.x & 63;
@@ -176,15 +185,6 @@ void resident_train_kernel(ResidentArgs a)
             }
         }
     }
-#ifdef MFCD_TRACE
-    u64 dbg_t_arrive = 0;
-    int dbg_nhit = 0;
-#endif
-#ifdef MFCD_STAMPS
-    [[maybe_unused]] u64 dbg_rt_age = 0, dbg_rt_n = 0;
-    u64 dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const u64 t_start = STAMP();
-#endif
 
     auto batch_size = [&](int step) {
         const int64_t pos0 = (int64_t)step * a.B;
@@ -199,33 +199,62 @@ void resident_train_kernel(ResidentArgs a)
         M.mj = __ballot(valid && rj >= Rlo && rj < Rhi);
         return M;
     };
-    // first register of global row R (one of mine): wave-uniform
-    auto reg_of = [&](int R) { return D >= 64 ? (R - Rlo) * S : (R - Rlo) / RPR; };
+    // first register of my LOCAL row lr (virtual row Rlo + lr): wave-uniform
+    auto reg_of = [&](int lr) { return D >= 64 ? lr * S : lr / RPR; };
 
-    // write row R (mine) as tagged granules into mailbox slot (pos*3 + role)
-    auto store_row = [&](int R, int64_t slot, unsigned tag) {
+    // a bounded wait expired (or somebody else's did): make it known and remember who gave up first
+    auto give_up = [&](int step, int64_t pos, int what) {
+        int *const status = a.cold->status;
+        if (lane == 0) {
+            if (__hip_atomic_exchange(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && a.dbg) {
+                a.dbg[0] = (u64)gw; a.dbg[1] = (u64)step; a.dbg[2] = (u64)pos; a.dbg[3] = (u64)what;
+            }
+        }
+    };
+    // one failed poll: returns true when the wave must give up (limit reached, or the abort word is set)
+    auto poll_failed = [&](unsigned &spins, unsigned &limit) -> bool {
+        if (spins == 0) limit = (unsigned)a.cold->spin_limit;   // first failed poll: the limit lives behind the cold pointer
+        ++spins;
+        if (spins > limit || (spins & 255u) == 0) {   // rare
+            if (spins > limit ||
+                __hip_atomic_load(a.cold->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                return true;
+        }
+        return false;
+    };
+
+    // write my local row lr as tagged granules into mailbox slot (pos*3 + role)
+    auto store_row = [&](int lr, int64_t slot, unsigned tag) {
         u64 *dst = a.mailbox + slot * D;
-        const int q0 = reg_of(R);
+        const int q0 = reg_of(lr);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             if (q >= q0 && q < q0 + S) {
                 if constexpr (D >= 64) {
                     store_granule(dst + (q - q0) * 64 + lane, tag, p[q]);
                 } else {
-                    if (lane / D == (R - Rlo) % RPR) store_granule(dst + lcol, tag, p[q]);
+                    if (lane / D == lr % RPR) store_granule(dst + lcol, tag, p[q]);
                 }
             }
         }
     };
 
-    // One sample (lane tl of chunk `base` of batch k) that touches my rows: fetch the other rows, form g,
-    // accumulate the row gradients of my rows into gr[].  Returns false when a bounded wait expired.
-    // `hs` is the sample itself (wave-uniform), `M`/`tl` say which of its rows are mine.
-    auto process_hit = [&](const mfcd_sample &hs, const Masks &M, int tl, int64_t pos, unsigned tag,
-                           float inv_batch) -> bool {
-        const int rows[3] = {hs.u, hs.i, hs.j};
-        const bool own[3] = {(bool)((M.mu >> tl) & 1ull), (bool)((M.mi >> tl) & 1ull), (bool)((M.mj >> tl) & 1ull)};
-        const float zz = hs.z;
+    // granules requested ONE STEP AHEAD for the first hit of the next step (look-ahead form): pf_key names the entry
+    [[maybe_unused]] u64 pf[3][S];
+    [[maybe_unused]] unsigned pf_key = kEventNone;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) pf[r][s2] = 0ull;
+
+    // One sample that names rows of mine (own0..2: which roles; lr0..2: my local rows of those roles): fetch the other
+    // rows, form g, accumulate the row gradients of my rows.  `pos` is the sample's position in the call, `tag` its
+    // step's tag.  pre: the foreign granules were requested a step ahead and sit in pf.  Returns false when a bounded
+    // wait expired.
+    auto process_hit = [&](bool own0, bool own1, bool own2, int lr0, int lr1, int lr2, float zz, int64_t pos,
+                           unsigned tag, float inv_batch, bool pre, int step) -> bool {
+        const bool own[3] = {own0, own1, own2};
+        const int lrs[3] = {lr0, lr1, lr2};
         const u64 *slot = a.mailbox + pos * 3 * D;
 
         // the three rows in gathered layout (zero beyond column D)
@@ -236,7 +265,7 @@ void resident_train_kernel(ResidentArgs a)
             for (int s2 = 0; s2 < S; ++s2) row[r][s2] = 0.0f;
             if (!own[r]) continue;
             // a row of mine comes straight from my registers
-            const int q0 = reg_of(rows[r]);
+            const int q0 = reg_of(lrs[r]);
             if constexpr (D >= 64) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q)
@@ -245,16 +274,13 @@ void resident_train_kernel(ResidentArgs a)
                 float sel = 0.0f;
 #pragma unroll
                 for (int q = 0; q < Q; ++q) sel = (q == q0) ? p[q] : sel;
-                const float v = __shfl(sel, ((rows[r] - Rlo) % RPR) * D + lcol, MFCD_WAVE);
+                const float v = __shfl(sel, (lrs[r] % RPR) * D + lcol, MFCD_WAVE);
                 row[r][0] = lane < D ? v : 0.0f;
             }
         }
-        // rows owned by other waves: poll their granules until every tag is this step's
+        // rows owned by other waves: their granules, polled until every tag is this step's
         unsigned spins = 0, limit = 0;
-#ifdef MFCD_TRACE
-        dbg_t_arrive = (u64)__builtin_amdgcn_s_memrealtime();
-#endif
-        [[maybe_unused]] const u64 t_poll0 = STAMP();
+        bool have = pre;
         while (true) {
             bool ok = true;
 #pragma unroll
@@ -264,62 +290,31 @@ void resident_train_kernel(ResidentArgs a)
                 for (int s2 = 0; s2 < S; ++s2) {
                     const int c = lane + 64 * s2;
                     if (c < D) {
-                        const u64 gq = load_granule(slot + (int64_t)r * D + c);
+                        const u64 gq = have ? pf[r][s2] : load_granule(slot + (int64_t)r * D + c);
                         ok = ok && ((unsigned)(gq >> 32) == tag);
                         row[r][s2] = __uint_as_float((unsigned)gq);
                     }
                 }
             }
             if (__all(ok)) break;
-            if (spins == 0) limit = (unsigned)a.cold->spin_limit;   // first failed poll: the limit lives behind the cold pointer
-            ++spins;
-            if (spins > limit || (spins & 255u) == 0) {   // rare
-                int *const status = a.cold->status;
-                if (spins > limit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                    if (lane == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return false;
-                }
+            have = false;
+            if (poll_failed(spins, limit)) {
+                give_up(step, pos, (own0 ? 1 : 0) | (own1 ? 2 : 0) | (own2 ? 4 : 0));
+                return false;
             }
         }
-        [[maybe_unused]] const u64 t_poll1 = STAMP();
-        DBG_ADD(1, t_poll1 - t_poll0);
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-        if (spins > 0) {   // waited: how old is the publish, and was it issued after I started polling ?
-            const u64 now_rt = (u64)__builtin_amdgcn_s_memrealtime();
-            u64 newest = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-                if (!own[r]) {
-                    const u64 tp = __hip_atomic_load(a.mailbox + (int64_t)a.N * 3 * D + pos * 3 + r, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                    newest = tp > newest ? tp : newest;
-                }
-            dbg_rt_age += now_rt - newest;                      // success time - (latest) publish time, 10 ns units
-            dbg_rt_n += 1;
-        }
-#ifdef MFCD_TRACE
-        // event trace (tools/trace_resident.py): one 32-byte record per hit behind the publish-time array:
-        // {sample position | own flags << 56, arrival (real-time clock, 10 ns), poll success, spins}
-        if (lane == 0 && dbg_nhit < 128) {
-            u64 *rec = a.mailbox + (int64_t)a.N * 3 * D + (int64_t)a.N * 3 + ((int64_t)gw * 128 + dbg_nhit) * 4;
-            rec[0] = (u64)pos | ((u64)(own[0] | (own[1] << 1) | (own[2] << 2)) << 56);
-            rec[1] = dbg_t_arrive;
-            rec[2] = (u64)__builtin_amdgcn_s_memrealtime();
-            rec[3] = spins;
-        }
-        dbg_nhit += 1;
-#endif
-#endif
-        DBG_ADD(5, 1);
-        DBG_ADD(6, spins);
 
         float acc = 0.0f;
 #pragma unroll
         for (int s2 = 0; s2 < S; ++s2) acc += row[0][s2] * (row[1][s2] - row[2][s2]);
         const float pr = sigmoid_f32(wave_sum64(acc));
         const float g = bce_sigmoid_backward_f32(pr, zz, inv_batch);
-        // u's owner records the sigmoid output; the BCE term is formed by the finalize kernel (off this path)
-        if (own[0] && lane == 0) a.loss_terms[pos] = pr;
+        // u's owner records the sigmoid output; the BCE term is formed off this path (in-launch batch means of the
+        // look-ahead form, batch_mean_kernel otherwise)
+        if (own[0] && lane == 0) {
+            if constexpr (LOOK > 0) store_granule((u64 *)a.loss_terms + pos, tag, pr);
+            else ((float *)a.loss_terms)[pos] = pr;
+        }
 
         float du[S], dv[S];  // g*(V[i]-V[j]) and g*U[u] in gathered layout
 #pragma unroll
@@ -336,26 +331,25 @@ void resident_train_kernel(ResidentArgs a)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 if (!own[r]) continue;
-                const int q0 = reg_of(rows[r]);
+                const int q0 = reg_of(lrs[r]);
                 if constexpr (D >= 64) {
 #pragma unroll
                     for (int s2 = 0; s2 < S; ++s2)
                         lgr[(q0 + s2) * 64 + lane] += r == 0 ? du[s2] : (r == 1 ? dv[s2] : -dv[s2]);
                 } else {
-                    if (lane / D == (rows[r] - Rlo) % RPR) lgr[q0 * 64 + lane] += r == 0 ? du[0] : (r == 1 ? dv[0] : -dv[0]);
+                    if (lane / D == lrs[r] % RPR) lgr[q0 * 64 + lane] += r == 0 ? du[0] : (r == 1 ? dv[0] : -dv[0]);
                 }
             }
         } else {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const int rowq = Rlo + (q * 64 + lane) / D;
+                const int rowq = (q * 64 + lane) / D;          // local row of this lane's element of register q
                 const int sq = D >= 64 ? (q * 64 % D) / 64 : 0;
-                if (own[0] && rowq == rows[0]) gr[q] += du[sq];
-                if (own[1] && rowq == rows[1]) gr[q] += dv[sq];
-                if (own[2] && rowq == rows[2]) gr[q] += -dv[sq];
+                if (own[0] && rowq == lrs[0]) gr[q] += du[sq];
+                if (own[1] && rowq == lrs[1]) gr[q] += dv[sq];
+                if (own[2] && rowq == lrs[2]) gr[q] += -dv[sq];
             }
         }
-        DBG_ADD(2, STAMP() - t_poll1);
         return true;
     };
 
@@ -387,333 +381,10 @@ void resident_train_kernel(ResidentArgs a)
         }
     };
 
-    if constexpr (LOOK > 0) {
-        // ================= B <= 64: look-ahead publishing over a window of LOOK batches =================
-        // Hot path per step and wave (no hit, no publish candidate — about nine wave-steps in ten): one prefetched
-        // 16-byte record load, one ballot, a handful of scalar moves, Adam on the slice.  Only ONE 64-bit mask per
-        // window batch lives in registers ("some sample of that batch touches a row of mine"); role masks and the
-        // records themselves are re-derived from a reload only when such a sample exists.
-        constexpr int W = LOOK;
-        const int N32 = (int)a.N;                                  // host guarantees N + 64*(W+2) < 2^31
-        const unsigned rcnt = (unsigned)(Rhi - Rlo);   // my rows: virtual ids [Rlo, Rlo + rcnt)
-        // this lane's record of batch `step`: branch-free (clamped address, then inert ids for lanes past the batch
-        // or past the stream), 32-bit byte offset from a scalar base
-        const char *const sbase = (const char *)a.samples;
-        auto load_rec = [&](int step) {
-            const int pos = step * a.B + lane;
-            const bool valid = lane < a.B && pos < N32;
-            const unsigned off = (unsigned)(valid ? pos : 0) * 16u;
-            mfcd_sample s = *(const mfcd_sample *)(sbase + off);
-            s.u = valid ? s.u : -0x40000000;
-            s.i = valid ? s.i : -0x40000000;
-            s.j = valid ? s.j : -0x40000000;
-            return s;
-        };
-        auto role_masks = [&](const mfcd_sample &s) {
-            Masks M;
-            M.mu = __ballot((unsigned)(s.u - Rlo) < rcnt);
-            M.mi = __ballot((unsigned)(s.i - Rlo) < rcnt);
-            M.mj = __ballot((unsigned)(s.j - Rlo) < rcnt);
-            return M;
-        };
-        auto lane_sample = [&](const mfcd_sample &s, int tl) {     // record of lane tl as wave-uniform values
-            mfcd_sample r;
-            r.u = __builtin_amdgcn_readlane(s.u, tl);
-            r.i = __builtin_amdgcn_readlane(s.i, tl);
-            r.j = __builtin_amdgcn_readlane(s.j, tl);
-            r.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.z), tl));
-            return r;
-        };
-        auto touches = [&](const mfcd_sample &s, int R) {          // does the batch held in `s` touch virtual row R ?
-            return __ballot(s.u == R || s.i == R || s.j == R) != 0ull;
-        };
-
-        // Which batches touch a row of mine is known before the launch (resident_translate_kernel: one pass over the
-        // call's samples).  A sliding window over such a bit string — bit b <-> batch j + b, j = the step just finished —
-        // replaces a per-step record load + range test + ballot per wave (every wave scanning every batch).
-        // Waves of up to 4 rows keep one window PER ROW (a.touch then holds one string per virtual row): which row is
-        // due for publishing, and for which step, is then decided with scalar bit tests alone, and the publish path
-        // fetches only the records of the batches it actually publishes for.
-        constexpr int RPW = EW / D;                 // rows per wave
-        constexpr bool ROWWIN = RPW <= 4;
-        constexpr int NWIN = ROWWIN ? RPW : 1;
-        const int gws = __builtin_amdgcn_readfirstlane(gw);
-        const unsigned *tw[NWIN];
-        u64 winR[NWIN];
-        const int KW0 = (int)a.cold->KW;
-#pragma unroll
-        for (int r = 0; r < NWIN; ++r) {
-            tw[r] = a.cold->touch + (size_t)(ROWWIN ? gws * RPW + r : gws) * KW0;
-            // (the strings are wave-uniform data, but they are written at the end of this kernel, so the compiler issues
-            // a vector load for them; without the readfirstlane the windows live in VGPRs and every test on them below
-            // becomes exec-mask control flow: that was 56 scalar instructions per wave-step)
-            winR[r] = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)tw[r][0]) << 1;   // j = -1: "batch -1" is empty
-        }
-        u64 win = winR[0];                          // any of my rows
-#pragma unroll
-        for (int r = 1; r < NWIN; ++r) win |= winR[r];
-        int fill = 33, widx = 1;     // bits 0 .. fill-1 of the windows are valid; the next dword of a string goes to bit `fill`
-
-        // publish, from the state after step j, every (k, R) whose turn it is (see the template comment)
-        // phase (per-row windows only): 0 everything, from the state after step j (the initial call);
-        //   1 BEFORE step j's own hits and update: the rows batch j does not touch — their value after step j is a
-        //     dense-only update away, so it is published now and does not wait behind this wave's hit of the step;
-        //   2 after the update: the rows batch j touched.
-        auto publish_phase = [&](int j, bool first, int phase, const StepScalars &sc_j) {
-            u64 cand = win & (1ull << W);
-            if (first || (win & 1ull)) cand |= win & ((1ull << W) - 2ull);   // bits 1 .. W-1
-            if (phase == 1) cand = win & (1ull << W);
-            if (phase == 2 && !(win & 1ull)) cand = 0ull;
-            if (__builtin_expect(cand == 0ull, 1)) return;         // the common case (laid out as the fall-through)
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-            const u64 t_pub0 = STAMP();
-#endif
-            if constexpr (ROWWIN) {
-                // per-row windows: (row r, step k = j + kk) is due iff batch k touches the row, no batch in (j, k) does,
-                // and either k has just entered the window (kk == W) or the row was touched by batch j itself (its
-                // value for k could not be known earlier) — the same rule as below, read off the bit strings
-                StepScalars scw[W];
-                bool have_sc = false;
-#pragma unroll
-                for (int r = 0; r < NWIN; ++r) {
-                    const u64 wr = winR[r];
-                    const bool fresh = first || (wr & 1ull);
-                    if (phase == 1 && (wr & 1ull)) continue;               // touched by batch j: after the update
-                    if (phase == 2 && !(wr & 1ull)) continue;              // done before the update
-#pragma unroll
-                    for (int kk = 1; kk <= W; ++kk) {
-                        const int k = j + kk;
-                        if (!((wr >> kk) & 1ull) || k >= a.K) continue;
-                        if (wr & ((1ull << kk) - 2ull)) continue;          // touched again in (j, k): published later
-                        if (kk < W && !fresh) continue;                    // published when k entered the window
-                        const int R = Rlo + r;
-                        const mfcd_sample rk = load_rec(k);
-                        if (!have_sc) {                                    // roll-forward scalars, same burst
-#pragma unroll
-                            for (int b2 = 1; b2 < W; ++b2) scw[b2] = a.sc[(j + b2) < a.K ? (j + b2) : a.K];
-                            have_sc = true;
-                        }
-                        // roll the registers of row R forward over steps j+1 .. k-1 (dense-only updates)
-                        const int q0 = reg_of(R);
-                        float pp[S], mm1[S], mm2[S];
-#pragma unroll
-                        for (int s2 = 0; s2 < S; ++s2) pp[s2] = mm1[s2] = mm2[s2] = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < Q; ++q) {
-                            if (q >= q0 && q < q0 + S) {
-                                const int s2 = D >= 64 ? (q * 64 % D) / 64 : 0;
-                                pp[s2] = p[q];
-                                mm1[s2] = m1[q];
-                                mm2[s2] = m2[q];
-                            }
-                        }
-                        if (phase == 1) {                                  // step j itself: dense-only for this row
-#pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) {
-                                adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, sc_j);
-                                pp[s2] = post(pp[s2]);
-                            }
-                        }
-#pragma unroll
-                        for (int b2 = 1; b2 < kk; ++b2) {
-#pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) {
-                                adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b2]);
-                                pp[s2] = post(pp[s2]);
-                            }
-                        }
-                        const u64 mr[3] = {(u64)__ballot(rk.u == R), (u64)__ballot(rk.i == R), (u64)__ballot(rk.j == R)};
-                        const unsigned tag = a.tag_base + (unsigned)k + 1u;
-#pragma unroll
-                        for (int role = 0; role < 3; ++role) {
-                            u64 pm = mr[role];
-                            while (pm) {
-                                const int tl = __ffsll((long long)pm) - 1;
-                                pm &= pm - 1;
-                                u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + role) * D;
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-                                if (lane == 0)   // publish time (100 MHz real-time clock), behind the mailbox
-                                    __hip_atomic_store(a.mailbox + (int64_t)a.N * 3 * D + ((int64_t)k * a.B + tl) * 3 + role,
-                                                       (u64)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-#endif
-                                if constexpr (D >= 64) {
-#pragma unroll
-                                    for (int s2 = 0; s2 < S; ++s2) store_granule(dst + s2 * 64 + lane, tag, pp[s2]);
-                                } else {
-                                    if (lane / D == (R - Rlo) % RPR) store_granule(dst + lcol, tag, pp[0]);
-                                }
-                            }
-                        }
-                    }
-                }
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-                DBG_ADD(4, STAMP() - t_pub0);
-                DBG_ADD(7, 1);
-#endif
-                return;
-            }
-            // slow path: bring the whole window's records in with ONE burst of independent loads
-            mfcd_sample wrec[W + 1];
-#pragma unroll
-            for (int b2 = 0; b2 <= W; ++b2) wrec[b2] = load_rec(j + b2 >= 0 ? j + b2 : a.K + 1);
-            // the per-step scalars of the roll-forward travel in the same burst (inside the loops below each would be a
-            // dependent load on the publish path); the table holds K+1 entries
-            StepScalars scw[W];
-#pragma unroll
-            for (int b2 = 1; b2 < W; ++b2) scw[b2] = a.sc[(j + b2) < a.K ? (j + b2) : a.K];
-#pragma unroll
-            for (int kk = 1; kk <= W; ++kk) {
-                const int k = j + kk;
-                if (!((win >> kk) & 1ull) || k >= a.K) continue;
-                if (kk < W && !first && !(win & 1ull)) continue;   // none of my rows was touched by batch j
-                const mfcd_sample rk = wrec[kk];
-                const Masks Mk = role_masks(rk);
-                u64 pm = Mk.mu | Mk.mi | Mk.mj;
-                while (pm) {
-                    const int tl = __ffsll((long long)pm) - 1;
-                    pm &= pm - 1;
-                    const mfcd_sample sk = lane_sample(rk, tl);
-                    const int rows[3] = {sk.u, sk.i, sk.j};
-                    const bool fl[3] = {(bool)((Mk.mu >> tl) & 1ull), (bool)((Mk.mi >> tl) & 1ull),
-                                        (bool)((Mk.mj >> tl) & 1ull)};
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        if (!fl[r]) continue;
-                        const int R = rows[r];
-                        bool later_touch = false;   // a batch in (j, k) touches R -> published after that step instead
-#pragma unroll
-                        for (int b2 = 1; b2 < kk; ++b2) later_touch = later_touch | touches(wrec[b2], R);
-                        if (later_touch) continue;
-                        if (kk < W && !first && !touches(wrec[0], R)) continue;  // already published when k entered the window
-                        // roll the registers of row R forward over steps j+1 .. k-1 (dense-only updates)
-                        const int q0 = reg_of(R);
-                        float pp[S], mm1[S], mm2[S];
-#pragma unroll
-                        for (int s2 = 0; s2 < S; ++s2) pp[s2] = mm1[s2] = mm2[s2] = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < Q; ++q) {
-                            if (q >= q0 && q < q0 + S) {
-                                const int s2 = D >= 64 ? (q * 64 % D) / 64 : 0;
-                                pp[s2] = p[q];
-                                mm1[s2] = m1[q];
-                                mm2[s2] = m2[q];
-                            }
-                        }
-#pragma unroll
-                        for (int b2 = 1; b2 < kk; ++b2) {
-#pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) {
-                                adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b2]);
-                                pp[s2] = post(pp[s2]);
-                            }
-                        }
-                        u64 *dst = a.mailbox + (((int64_t)k * a.B + tl) * 3 + r) * D;
-                        const unsigned tag = a.tag_base + (unsigned)k + 1u;
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-                        if (lane == 0)   // publish time (100 MHz real-time clock), behind the mailbox
-                            __hip_atomic_store(a.mailbox + (int64_t)a.N * 3 * D + ((int64_t)k * a.B + tl) * 3 + r,
-                                               (u64)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-#endif
-                        if constexpr (D >= 64) {
-#pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) store_granule(dst + s2 * 64 + lane, tag, pp[s2]);
-                        } else {
-                            if (lane / D == (R - Rlo) % RPR) store_granule(dst + lcol, tag, pp[0]);
-                        }
-                    }
-                }
-            }
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-            DBG_ADD(4, STAMP() - t_pub0);
-            DBG_ADD(7, 1);
-#endif
-        };
-
-        publish_phase(-1, true, 0, a.sc[0]);
-
-        StepScalars sc_cur = a.sc[0];
-        const StepScalars *sc_ptr = a.sc + 1;      // running pointer: the table holds K+1 entries (host pads one)
-        for (int k = 0; k < a.K; ++k) {
-            // slide the windows: bit 0 becomes batch k
-            --fill;
-#pragma unroll
-            for (int r = 0; r < NWIN; ++r) winR[r] >>= 1;
-            if (__builtin_expect(fill < 16, 0)) {
-#pragma unroll
-                for (int r = 0; r < NWIN; ++r)
-                    winR[r] |= (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)tw[r][widx]) << fill;
-                ++widx;
-                fill += 32;
-            }
-            win = winR[0];
-#pragma unroll
-            for (int r = 1; r < NWIN; ++r) win |= winR[r];
-#if defined(MFCD_RES_EXP) && MFCD_RES_EXP == 1   // timing experiment (tools/): no per-step scalar load
-            const StepScalars sc_next = sc_cur;
-#else
-            const StepScalars sc_next = *sc_ptr++;
-#endif
-
-            if constexpr (!GRL) {
-#pragma unroll
-                for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
-            }
-            if constexpr (ROWWIN) publish_phase(k, false, 1, sc_cur);
-            // a wave with a hit or a fresh publish is on somebody's critical chain, the waves on the common path have
-            // slack: it issues ahead of them until its step is done
-            const bool urgent = (win & 1ull) != 0ull;
-            if (__builtin_expect(urgent, 0)) __builtin_amdgcn_s_setprio(3);
-            if (__builtin_expect((win & 1ull) != 0ull, 0)) {
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-                const u64 t_hit0 = STAMP();
-#endif
-                const mfcd_sample rk = load_rec(k);
-                const Masks M0 = role_masks(rk);
-                const int64_t pos0 = (int64_t)k * a.B;
-                const int bk = (N32 - k * a.B) < a.B ? (N32 - k * a.B) : a.B;
-                const float inv_batch = 1.0f / (float)bk;
-                u64 mask = M0.mu | M0.mi | M0.mj;
-                while (mask) {
-                    const int tl = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    // the abort decision is wave-uniform; saying so keeps the step loop free of exec-mask bookkeeping
-                    const bool ok = process_hit(lane_sample(rk, tl), M0, tl, pos0 + tl, a.tag_base + (unsigned)k + 1u, inv_batch);
-                    if (__builtin_amdgcn_readfirstlane((int)!ok)) return;
-                }
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-                DBG_ADD(3, STAMP() - t_hit0);
-#endif
-            }
-#if defined(MFCD_STAMPS) && MFCD_STAMPS == 2
-            step_update(urgent, sc_cur);
-            publish_phase(k, false, ROWWIN ? 2 : 0, sc_cur);
-            if (__builtin_expect(urgent, 0)) __builtin_amdgcn_s_setprio(0);
-#else
-            [[maybe_unused]] const u64 t_adam0 = STAMP();
-            step_update(urgent, sc_cur);
-            [[maybe_unused]] const u64 t_adam1 = STAMP();
-            DBG_ADD(3, t_adam1 - t_adam0);
-            publish_phase(k, false, ROWWIN ? 2 : 0, sc_cur);
-            if (__builtin_expect(urgent, 0)) __builtin_amdgcn_s_setprio(0);
-            DBG_ADD(4, STAMP() - t_adam1);
-#endif
-            sc_cur = sc_next;
-        }
-        // my touch strings are read by nobody else: leave them all-zero for the next launch's prologue (atomicOr).
-        // Their address is re-derived from fresh scalar loads so that nothing stays live across the step loop for it.
-        {
-            const ResidentCold *cz = a.cold;
-            asm volatile("" : "+s"(cz));
-            unsigned *const tz = cz->touch;
-            const int KWz = (int)cz->KW;
-#pragma unroll
-            for (int r = 0; r < NWIN; ++r)
-                for (int w = lane; w < KWz; w += MFCD_WAVE) tz[(size_t)(ROWWIN ? gws * RPW + r : gws) * KWz + w] = 0u;
-        }
-    } else {
-        // ================= any B: chunked scan, publish after the whole slice is updated =================
+    // ================= generic loop (any B): chunked scan, rows published right before their use =================
+    // The whole launch of the LOOK = 0 instantiations, and the whole launch of a single WAVE of the look-ahead form whose
+    // event list did not fit.  Returns false when a bounded wait expired.
+    auto generic_loop = [&]() -> bool {
         auto publish = [&](int step) {
             const int64_t pos0 = (int64_t)step * a.B;
             const int Bk = batch_size(step);
@@ -725,9 +396,9 @@ void resident_train_kernel(ResidentArgs a)
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     const int64_t slot0 = (pos0 + base + tl) * 3;
-                    if ((M.mu >> tl) & 1ull) store_row(__shfl(s.u, tl, MFCD_WAVE), slot0 + 0, a.tag_base + (unsigned)step + 1u);
-                    if ((M.mi >> tl) & 1ull) store_row(__shfl(s.i, tl, MFCD_WAVE), slot0 + 1, a.tag_base + (unsigned)step + 1u);
-                    if ((M.mj >> tl) & 1ull) store_row(__shfl(s.j, tl, MFCD_WAVE), slot0 + 2, a.tag_base + (unsigned)step + 1u);
+                    if ((M.mu >> tl) & 1ull) store_row(__shfl(s.u, tl, MFCD_WAVE) - Rlo, slot0 + 0, a.tag_base + (unsigned)step + 1u);
+                    if ((M.mi >> tl) & 1ull) store_row(__shfl(s.i, tl, MFCD_WAVE) - Rlo, slot0 + 1, a.tag_base + (unsigned)step + 1u);
+                    if ((M.mj >> tl) & 1ull) store_row(__shfl(s.j, tl, MFCD_WAVE) - Rlo, slot0 + 2, a.tag_base + (unsigned)step + 1u);
                 }
             }
         };
@@ -750,30 +421,286 @@ void resident_train_kernel(ResidentArgs a)
                 while (mask) {
                     const int tl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    mfcd_sample hs;
-                    hs.u = __shfl(s.u, tl, MFCD_WAVE);
-                    hs.i = __shfl(s.i, tl, MFCD_WAVE);
-                    hs.j = __shfl(s.j, tl, MFCD_WAVE);
-                    hs.z = __shfl(s.z, tl, MFCD_WAVE);
-                    const bool ok = process_hit(hs, M, tl, pos0 + base + tl, a.tag_base + (unsigned)k + 1u, inv_batch);
-                    if (__builtin_amdgcn_readfirstlane((int)!ok)) return;
+                    const int hu = __shfl(s.u, tl, MFCD_WAVE) - Rlo, hi = __shfl(s.i, tl, MFCD_WAVE) - Rlo,
+                              hj = __shfl(s.j, tl, MFCD_WAVE) - Rlo;
+                    const float hz = __shfl(s.z, tl, MFCD_WAVE);
+                    const bool ok = process_hit((bool)((M.mu >> tl) & 1ull), (bool)((M.mi >> tl) & 1ull),
+                                                (bool)((M.mj >> tl) & 1ull), hu, hi, hj, hz, pos0 + base + tl,
+                                                a.tag_base + (unsigned)k + 1u, inv_batch, false, k);
+                    if (__builtin_amdgcn_readfirstlane((int)!ok)) return false;
                 }
             }
             step_update(any_hit, sc);
             if (k + 1 < a.K) publish(k + 1);
         }
+        return true;
+    };
+
+    bool alive = true;   // false: a bounded wait expired; the launch is winding down (parameters undefined, status set)
+
+    if constexpr (LOOK > 0) {
+        // ================= B <= 64: look-ahead publishing driven by the wave's event list =================
+        constexpr int W = LOOK;
+        const int N32 = (int)a.N;                                  // host guarantees N + 64*(W+2) < 2^31
+        const int gws = __builtin_amdgcn_readfirstlane(gw);
+        const int tshift = (int)a.cold->tshift;
+        const int NCH = ((a.K - 1) >> tshift) + 1;                 // chunks of this call
+
+        // ---- does every list of mine fit ?  (wave-uniform) ----
+        bool fits = true;
+        {
+            const unsigned *cnt = a.cold->ev_cnt + (size_t)gws * (size_t)a.cold->nch_cap;
+            for (int c = lane; c < NCH; c += MFCD_WAVE) fits = fits && cnt[c] <= (unsigned)kEventCap;
+            fits = __all(fits);
+        }
+        if (!__builtin_amdgcn_readfirstlane((int)fits)) {
+            alive = generic_loop();
+        } else {
+            // this lane's entry of the current chunk's list, sorted by word 0 (kEventNone past the end)
+            unsigned ekey = kEventNone, erow = 0u;
+            float ez = 0.0f;
+            int chunk_end = 0;                                     // first step that is not in the current chunk
+
+            auto load_chunk = [&](int c) {
+                // (pointers re-derived from fresh scalar loads: nothing stays live across the step loop for them)
+                const ResidentCold *cz = a.cold;
+                asm volatile("" : "+s"(cz));
+                const size_t li = (size_t)gws * (size_t)cz->nch_cap + (size_t)c;
+                const uint4 e = cz->ev_ent[li * kEventCap + lane];   // past the count: stale bytes, masked below
+                const unsigned n_raw = cz->ev_cnt[li];
+                const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_raw);
+                const unsigned key = (unsigned)lane < n ? e.x : kEventNone;
+                // rank of my key among the n entries (keys are unique: one entry per (step, slot)); lanes past the
+                // end keep their place, so `dest` is a permutation of the 64 lanes
+                unsigned rank = 0u;
+                for (unsigned l = 0; l < n; ++l) {
+                    const unsigned kl = (unsigned)__builtin_amdgcn_readlane((int)key, (int)l);
+                    rank += kl < key ? 1u : 0u;
+                }
+                const int dest = (int)((unsigned)lane < n ? rank : (unsigned)lane) << 2;
+                ekey = (unsigned)__builtin_amdgcn_ds_permute(dest, (int)key);
+                erow = (unsigned)__builtin_amdgcn_ds_permute(dest, (int)e.y);
+                ez = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest, (int)e.z));
+                const int ce = (c + 1) << tshift;
+                chunk_end = ce < a.K ? ce : a.K;
+            };
+            // lanes whose entry's step is < x: a prefix of the sorted list
+            auto lt = [&](int x) -> u64 { return __ballot((int)(ekey >> 9) < x); };
+            // step of the first entry whose step is >= x (0x7FFFFF: none)
+            auto first_step_ge = [&](int x) -> int {
+                const int idx = __builtin_popcountll(lt(x));
+                return idx < 64 ? (int)((unsigned)__builtin_amdgcn_readlane((int)ekey, idx) >> 9) : 0x7FFFFF;
+            };
+            // lanes whose entry names my local row lr (in a role I own)
+            auto rowmask = [&](int lr) -> u64 {
+                const bool t = ((ekey & 1u) && (int)(erow & 1023u) == lr) ||
+                               ((ekey & 2u) && (int)((erow >> 10) & 1023u) == lr) ||
+                               ((ekey & 4u) && (int)((erow >> 20) & 1023u) == lr);
+                return __ballot(t);
+            };
+
+            // Publish pass.  The registers hold the state after step jbase (-1: the initial state).  Entry e (step ke,
+            // role r, my row lr) is due now iff no entry with a step in (jbase, ke) names lr, and
+            //   fresh  (after the update of a hit step / at the start): ke <= jbase + W and batch jbase named lr (its value
+            //          for ke could not be known earlier; at the start every row counts as just touched);
+            //   !fresh (before the hits and the update of step jbase + 1): ke == jbase + 1 + W — the entry has just
+            //          entered the window (a row that batch jbase + 1 names is in (jbase, ke) and waits for its update).
+            // Every (entry, role) is published exactly once: by the step of its row's previous touch if that lies
+            // within W steps, else W steps ahead.  The row is rolled forward over steps jbase+1 .. ke-1 (dense-only
+            // updates, same arithmetic in the same order as the slice will see: identical bits).
+            auto publish_pass = [&](int jbase, bool fresh) {
+                const u64 lo = lt(jbase + 1);                      // steps <= jbase
+                u64 cand = fresh ? (lt(jbase + W + 1) & ~lo) : (lt(jbase + W + 2) & ~lt(jbase + W + 1));
+                if (cand == 0ull) return;
+                const u64 at_j = (fresh && jbase >= 0) ? (lo & ~lt(jbase)) : 0ull;
+                StepScalars scw[W];                                // scalars of steps jbase+1 .. jbase+W (table: K+1 entries)
+#pragma unroll
+                for (int b = 0; b < W; ++b) scw[b] = a.sc[(jbase + 1 + b) < a.K ? (jbase + 1 + b) : a.K];
+                while (cand) {
+                    const int l = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)ekey, l);
+                    const unsigned row_l = (unsigned)__builtin_amdgcn_readlane((int)erow, l);
+                    const int ke = (int)(key_l >> 9);
+                    if (ke >= a.K) continue;                       // (boundary copies past the end of the call: none exist)
+                    const int tl = (int)((key_l >> 3) & 63u);
+                    const u64 between = lt(ke) & ~lo;              // steps in (jbase, ke)
+#pragma unroll 1
+                    for (int r = 0; r < 3; ++r) {
+                        if (!((key_l >> r) & 1u)) continue;
+                        const int lr = (int)((row_l >> (10 * r)) & 1023u);
+                        const u64 rm = rowmask(lr);
+                        if (rm & between) continue;
+                        if (fresh && jbase >= 0 && !(rm & at_j)) continue;
+                        // roll the registers of my row lr forward over steps jbase+1 .. ke-1
+                        const int q0 = reg_of(lr);
+                        float pp[S], mm1[S], mm2[S];
+#pragma unroll
+                        for (int s2 = 0; s2 < S; ++s2) pp[s2] = mm1[s2] = mm2[s2] = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            if (q >= q0 && q < q0 + S) {
+                                const int s2 = D >= 64 ? (q * 64 % D) / 64 : 0;
+                                pp[s2] = p[q];
+                                mm1[s2] = m1[q];
+                                mm2[s2] = m2[q];
+                            }
+                        }
+                        const int nroll = ke - 1 - jbase;          // 0 .. W
+#pragma unroll
+                        for (int b = 0; b < W; ++b) {
+                            if (b < nroll) {
+#pragma unroll
+                                for (int s2 = 0; s2 < S; ++s2) {
+                                    adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b]);
+                                    pp[s2] = post(pp[s2]);
+                                }
+                            }
+                        }
+                        u64 *dst = a.mailbox + (((int64_t)ke * a.B + tl) * 3 + r) * D;
+                        const unsigned tag = a.tag_base + (unsigned)ke + 1u;
+                        if constexpr (D >= 64) {
+#pragma unroll
+                            for (int s2 = 0; s2 < S; ++s2) store_granule(dst + s2 * 64 + lane, tag, pp[s2]);
+                        } else {
+                            if (lane / D == lr % RPR) store_granule(dst + lcol, tag, pp[0]);
+                        }
+                    }
+                }
+            };
+
+            // request, one step ahead, the foreign granules of the FIRST entry of step k1 (if there is one)
+            auto prefetch_for = [&](int k1) {
+                const int idx = __builtin_popcountll(lt(k1));
+                if (idx >= 64) return;
+                const unsigned key1 = (unsigned)__builtin_amdgcn_readlane((int)ekey, idx);
+                if ((int)(key1 >> 9) != k1) return;
+                const int tl = (int)((key1 >> 3) & 63u);
+                const u64 *slot = a.mailbox + ((int64_t)k1 * a.B + tl) * 3 * D;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if ((key1 >> r) & 1u) continue;
+#pragma unroll
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const int c = lane + 64 * s2;
+                        if (c < D) pf[r][s2] = load_granule(slot + (int64_t)r * D + c);
+                    }
+                }
+                pf_key = key1;
+            };
+            // the next step at which this wave has anything to do besides its dense update, seen from step k (> k)
+            auto next_event = [&](int k) -> int {
+                const int s_h = first_step_ge(k + 1);              // next hit: be there one step early (granule request)
+                const int ch = s_h - 1 > k ? s_h - 1 : k + 1;
+                const int cp = first_step_ge(k + W + 1) - W;       // next entry to enter the window
+                const int e = ch < cp ? ch : cp;
+                return e < chunk_end ? e : chunk_end;
+            };
+
+            load_chunk(0);
+            publish_pass(-1, true);
+            prefetch_for(0);
+            int next_evt = next_event(-1);
+
+            StepScalars sc_cur = a.sc[0];
+            const StepScalars *sc_ptr = a.sc + 1;      // running pointer: the table holds K+1 entries (host pads one)
+            int chunk = 0;
+            for (int k = 0; k < a.K; ++k) {
+                const StepScalars sc_next = *sc_ptr++;
+                if constexpr (!GRL) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
+                }
+                bool hit = false;
+                if (__builtin_expect(k == next_evt, 0)) {
+                    // a wave with an event is on somebody's critical chain, the waves on the common path have slack:
+                    // it issues ahead of them until its step is done
+                    __builtin_amdgcn_s_setprio(3);
+                    if (k == chunk_end) load_chunk(++chunk);
+                    publish_pass(k - 1, false);                    // entries that enter the window: step k + W
+                    u64 H = lt(k + 1) & ~lt(k);                    // my hits of this step, in batch order
+                    if (H) {
+                        hit = true;
+                        const int bk = (N32 - k * a.B) < a.B ? (N32 - k * a.B) : a.B;
+                        const float inv_batch = 1.0f / (float)bk;
+                        const unsigned tag = a.tag_base + (unsigned)k + 1u;
+                        while (H) {
+                            const int l = __ffsll((long long)H) - 1;
+                            H &= H - 1;
+                            const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)ekey, l);
+                            const unsigned row_l = (unsigned)__builtin_amdgcn_readlane((int)erow, l);
+                            const float z_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ez), l));
+                            const bool pre = key_l == pf_key;
+                            // the abort decision is wave-uniform; saying so keeps the step loop free of exec-mask bookkeeping
+                            const bool ok = process_hit((bool)(key_l & 1u), (bool)(key_l & 2u), (bool)(key_l & 4u),
+                                                        (int)(row_l & 1023u), (int)((row_l >> 10) & 1023u),
+                                                        (int)((row_l >> 20) & 1023u), z_l,
+                                                        (int64_t)k * a.B + (int)((key_l >> 3) & 63u), tag, inv_batch, pre, k);
+                            if (__builtin_amdgcn_readfirstlane((int)!ok)) { alive = false; break; }
+                        }
+                        pf_key = kEventNone;
+                        if (!alive) break;
+                    }
+                    prefetch_for(k + 1);
+                    next_evt = next_event(k);
+                    if (!hit) __builtin_amdgcn_s_setprio(0);
+                }
+                step_update(hit, sc_cur);
+                if (__builtin_expect(hit, 0)) {
+                    publish_pass(k, true);                         // rows batch k touched: their next use, if within W steps
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                sc_cur = sc_next;
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+
+        // ---- batch means, inside the launch: wave w forms the mean BCE of steps w, w + NW, ... from the tagged sigmoid
+        // outputs their u-owners recorded (same terms, same summation order as batch_mean_kernel).  Nobody waits for
+        // this wave, so the polls are off every critical chain; they end when the slowest owner has passed the step.
+        {
+            float *const loss_out = a.cold->loss_out;
+            if (loss_out != nullptr) {
+                for (int k = gws; k < a.K && alive; k += a.NW) {
+                    const int64_t off = (int64_t)k * a.B;
+                    const int b = (int)((a.N - off) < a.B ? (a.N - off) : a.B);
+                    const unsigned tag = a.tag_base + (unsigned)k + 1u;
+                    const float zz = lane < b ? a.samples[off + lane].z : 0.0f;
+                    unsigned spins = 0, limit = 0;
+                    float pr = 0.0f;
+                    while (true) {
+                        bool ok = true;
+                        if (lane < b) {
+                            const u64 gq = load_granule((const u64 *)a.loss_terms + off + lane);
+                            ok = (unsigned)(gq >> 32) == tag;
+                            pr = __uint_as_float((unsigned)gq);
+                        }
+                        if (__all(ok)) break;
+                        __builtin_amdgcn_s_sleep(8);
+                        if (poll_failed(spins, limit)) {
+                            give_up(k, off, 8);
+                            alive = false;
+                            break;
+                        }
+                    }
+                    if (!alive) break;
+                    float acc = lane < b ? bce_term_f32(pr, zz) : 0.0f;
+                    acc = wave_sum64(acc);
+                    if (lane == 0) loss_out[k] = acc / (float)b;
+                }
+            }
+        }
+        // my list counters are read by nobody else: leave them all-zero for the next launch's prologue (atomicAdd)
+        {
+            unsigned *const cnt = a.cold->ev_cnt + (size_t)gws * (size_t)a.cold->nch_cap;
+            for (int c = lane; c < NCH; c += MFCD_WAVE) cnt[c] = 0u;
+        }
+    } else {
+        alive = generic_loop();
     }
 
-#ifdef MFCD_STAMPS
-    dbg_acc[0] = STAMP() - t_start;
-#if MFCD_STAMPS == 2
-    dbg_acc[2] = dbg_rt_age;   // light mode: slot 2 = sum of (success - publish) over waited polls [10 ns], slot 6 spins
-    dbg_acc[5] = dbg_acc[5] | (dbg_rt_n << 32);   // high half: number of waited polls
-#endif
-    if (lane == 0 && a.dbg)
-        for (int x = 0; x < 8; ++x) a.dbg[(int64_t)gw * 8 + x] = dbg_acc[x];
-#endif
     // ---- write my slice back (the table pointers are re-read: they were not kept live across the loop) ----
+    // (after an expired wait the values are undefined but the status word says so; the store keeps the exit path single)
     const ResidentCold *cp = a.cold;
     asm volatile("" : "+s"(cp));   // opaque to the optimiser: forces fresh scalar loads instead of 12 live SGPRs
     const ResidentCold c = *cp;

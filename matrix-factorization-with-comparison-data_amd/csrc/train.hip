@@ -457,14 +457,17 @@ constexpr int kTagStepBits = 21;    // granule tag = launch id << 21 | (step + 1
 constexpr unsigned kMaxLaunchId = (1u << (32 - kTagStepBits)) - 1;
 
 // Fixed carve-up of a registered workspace (mfcd_train_workspace_init), a function of the CAPACITY it was planned for:
-//   status | dbg | stage (ResidentCold + K_cap+1 step scalars) | terms [N_cap] | touch strings (resident; kept all-zero
-//   between launches) | { U_alt, V_alt (streaming) } overlapping { translated samples, mailbox (resident) }
+//   status | dbg | stage (ResidentCold + K_cap+1 step scalars) | terms [N_cap] (8-byte tagged granules) | event-list
+//   counters (resident; kept all-zero between launches) | event-list entries |
+//   { U_alt, V_alt (streaming) } overlapping { translated samples, mailbox (resident) }
 // Every call with N <= N_cap and ceil(N/B) <= K_cap uses these offsets, so nothing has to be re-initialised per call.
 struct TrainLayout {
-    size_t dbg_off, stage_off, stage_bytes, terms_off, touch_off, touch_bytes;
+    size_t dbg_off, stage_off, stage_bytes, terms_off, evcnt_off, evcnt_bytes, event_off, event_bytes;
     size_t ualt_off, valt_off, xs_off, mailbox_off, mailbox_bytes, total;
     size_t alt_end;  // end of the streaming members of the union (U_alt, V_alt)
     int64_t K_cap;
+    int64_t nch_cap;                    // chunks per wave of the event lists
+    mfcd_detail::ResidentEvents ev;     // geometry of the event lists (tshift 0: none)
     bool resident;   // the resident regions exist
 };
 
@@ -494,13 +497,18 @@ TrainLayout train_layout(int64_t N_cap, int B, int n, int m, int d)
     L.stage_bytes = kColdBytes + sizeof(StepScalars) * (size_t)(L.K_cap + 1);   // one pad entry: the kernel reads step k+1
     off += align256(L.stage_bytes);
     L.terms_off = off;
-    off += align256(sizeof(float) * (size_t)Nc);
+    off += align256(sizeof(unsigned long long) * (size_t)Nc);
     L.mailbox_bytes = sizeof(unsigned long long) * (size_t)Nc * 3 * (size_t)d;
     L.resident = resident_feasible(n, m, d, device_cus()) && L.mailbox_bytes <= kMaxMailboxBytes &&
                  L.K_cap < ((int64_t)1 << 31) - 64;
-    L.touch_off = off;
-    L.touch_bytes = L.resident ? mfcd_detail::resident_touch_bytes(L.K_cap) : 0;
-    off += align256(L.touch_bytes);
+    L.ev = L.resident ? mfcd_detail::resident_events(B, n, m, d, device_cus()) : mfcd_detail::ResidentEvents{0, 0, 0};
+    L.nch_cap = L.ev.tshift ? mfcd_detail::resident_event_chunks(L.K_cap, L.ev.tshift) : 0;
+    L.evcnt_off = off;
+    L.evcnt_bytes = sizeof(unsigned) * (size_t)L.ev.waves * (size_t)L.nch_cap;
+    off += align256(L.evcnt_bytes);
+    L.event_off = off;
+    L.event_bytes = (size_t)16 * mfcd_detail::kResidentEventCap * (size_t)L.ev.waves * (size_t)L.nch_cap;
+    off += align256(L.event_bytes);
     // streaming members of the union
     size_t a_off = off;
     L.ualt_off = a_off;
@@ -552,6 +560,8 @@ struct WsState {
     int B = 0, n = 0, m = 0, d = 0;
     TrainLayout L{};
     unsigned launch_id = 0;    // resident launches so far (mod kMaxLaunchId): the tag base of the next one
+    bool terms_dirty = false;     // a call that keeps plain fp32 terms (streaming / local / generic resident) wrote the term
+                                  // region: zeroed before the next launch that reads it as tagged granules
     bool mailbox_dirty = false;   // a streaming-form call wrote U_alt / V_alt over the head of the mailbox (same union):
                                   // fp32 bit patterns there could pass for tagged granules, so the next resident launch
                                   // zeroes that prefix first
@@ -725,7 +735,7 @@ struct FormChoice {
     mfcd_detail::ResidentPlan rp;
 };
 
-FormChoice choose_form(bool f32, bool resident_planned, int64_t N, int B, int n, int m, int d)
+FormChoice choose_form(bool f32, bool resident_planned, int ev_tshift, int64_t N, int B, int n, int m, int d)
 {
     FormChoice c{};
     const int64_t nsteps = (N + B - 1) / B;
@@ -741,7 +751,7 @@ FormChoice choose_form(bool f32, bool resident_planned, int64_t N, int B, int n,
     bool resident_ok = false;
     if (resident_planned && g_train_path != 1 && N > 0 && nsteps <= 0x7fffffff &&
         nsteps + 1 < ((int64_t)1 << kTagStepBits)) {
-        c.rp = mfcd_detail::plan_resident(N, B, n, m, d, device_cus(), !f32);
+        c.rp = mfcd_detail::plan_resident(N, B, n, m, d, device_cus(), !f32, ev_tshift);
         resident_ok = c.rp.ok;
     }
     if (g_train_path == 2) {
@@ -777,33 +787,38 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     int *status = (int *)workspace;
 
     constexpr bool kF32 = sizeof(TP) == 4;   // bf16 factor tables: streaming or resident form (the local form is fp32 only)
-    const FormChoice fc = choose_form(kF32, L.resident, N, B, n, m, d);
+    const FormChoice fc = choose_form(kF32, L.resident, L.ev.tshift, N, B, n, m, d);
     if (fc.form < 0) return fc.form;
 
     if (fc.form == 2 || fc.form == 3) {
         // ---- persistent forms: ONE launch for all nsteps (resident.hip / local.hip) behind ONE prologue kernel ----
         const bool resident = fc.form == 2;
+        // look-ahead form (B <= 64): the batch means are formed inside the launch; otherwise by batch_mean_kernel
+        const bool means_inside = resident && fc.rp.lookahead > 0;
         StepScalars *sc_dev = (StepScalars *)(base + L.stage_off + kColdBytes);
-        float *terms = (float *)(base + L.terms_off);
+        void *terms = base + L.terms_off;
         StageSlot *slot = nullptr;
         const size_t need = kColdBytes + sizeof(StepScalars) * (size_t)(nsteps + 1);
         if (int rc = stage_acquire(*S, need, &slot)) return rc;
-        void **cold = (void **)slot->host;   // ResidentCold {U, V, mU, vU, mV, vV, status, spin limit}
+        void **cold = (void **)slot->host;   // ResidentCold (resident_kernel.h)
         cold[0] = U; cold[1] = V; cold[2] = mU; cold[3] = vU; cold[4] = mV; cold[5] = vV; cold[6] = status;
         cold[7] = (void *)(uintptr_t)mfcd_detail::g_tune.spin_limit;
-        cold[8] = base + L.touch_off;
-        cold[9] = (void *)(uintptr_t)mfcd_detail::resident_touch_words(nsteps);
-        for (int k = 10; k < 16; ++k) cold[k] = nullptr;
+        cold[8] = base + L.evcnt_off;
+        cold[9] = base + L.event_off;
+        cold[10] = (void *)(uintptr_t)L.nch_cap;
+        cold[11] = (void *)(uintptr_t)fc.rp.tshift;
+        cold[12] = means_inside ? (void *)loss_per_step : nullptr;
+        for (int k = 13; k < 16; ++k) cold[k] = nullptr;
         StepScalars *sc_host = (StepScalars *)((char *)slot->host + kColdBytes);
         for (int64_t k = 0; k <= nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
 
         mfcd_sample *xs = resident ? (mfcd_sample *)(base + L.xs_off) : nullptr;
-        unsigned *touch = (unsigned *)(base + L.touch_off);
         unsigned long long *mailbox = (unsigned long long *)(base + L.mailbox_off);
         unsigned tag_base = 0;
         if (resident) {
             if (S->launch_id >= kMaxLaunchId) {   // the launch ids wrap: forget every granule of the past, once
                 MFCD_HIP_TRY(hipMemsetAsync(mailbox, 0, L.mailbox_bytes, st));
+                MFCD_HIP_TRY(hipMemsetAsync(terms, 0, sizeof(unsigned long long) * (size_t)S->N_cap, st));
                 S->launch_id = 0;
             }
             tag_base = ++S->launch_id << kTagStepBits;
@@ -814,12 +829,18 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
                 }
                 S->mailbox_dirty = false;
             }
+            if (S->terms_dirty) {   // a form that keeps plain fp32 terms ran on this workspace: no stale bit pattern may
+                                    // pass for a tagged term
+                MFCD_HIP_TRY(hipMemsetAsync(terms, 0, sizeof(unsigned long long) * (size_t)S->N_cap, st));
+                S->terms_dirty = false;
+            }
         }
+        if (!means_inside) S->terms_dirty = true;
         const int rpw = resident ? 64 * fc.rp.Q / d : 0;
-        const int want_touch = resident && fc.rp.lookahead > 0;
-        if (int rc = mfcd_detail::launch_train_prologue(slot->host, slot->devview, base + L.stage_off, need, samples, N, B, n, m, rpw,
-                                                        mfcd_detail::resident_touch_words(nsteps), want_touch, xs, touch,
-                                                        st))
+        const int look = means_inside ? fc.rp.lookahead : 0;
+        if (int rc = mfcd_detail::launch_train_prologue(slot->host, slot->devview, base + L.stage_off, need, samples, N, B, n,
+                                                        m, rpw, fc.rp.tshift, look, L.nch_cap, xs,
+                                                        (unsigned *)(base + L.evcnt_off), base + L.event_off, st))
             return rc;
 
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -835,12 +856,13 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
                                                     terms, (unsigned long long *)(base + L.dbg_off), (int)nsteps, st);
         else
             rc = mfcd_detail::launch_local_steps((float *)U, (float *)V, mU, vU, mV, vV, samples, N, B, n, m, d, sc_dev,
-                                                 adam_static(beta1, beta2, eps, weight_decay), terms, (int)nsteps, st);
+                                                 adam_static(beta1, beta2, eps, weight_decay), (float *)terms,
+                                                 (int)nsteps, st);
         if (rc) return rc;
         if (timing_us) MFCD_HIP_TRY(hipEventRecord(e1, st));
-        if (loss_per_step) {
-            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms, samples, N, B,
-                               loss_per_step);
+        if (loss_per_step && !means_inside) {
+            hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, (const float *)terms, samples, N,
+                               B, loss_per_step);
             MFCD_HIP_TRY(hipGetLastError());
         }
         // the slot is free again once the prologue has read it; recorded behind the call's last launch so that the
@@ -859,7 +881,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     }
 
     // ---- streaming form: one launch per optimiser step ----
-    if (L.resident) S->mailbox_dirty = true;
+    if (L.resident) S->mailbox_dirty = S->terms_dirty = true;
     TP *Ualt = (TP *)(base + L.ualt_off);
     TP *Valt = (TP *)(base + L.valt_off);
     float *terms = (float *)(base + L.terms_off);
@@ -917,7 +939,7 @@ extern "C" int mfcd_train_plan_query(int64_t N, int B, int n, int m, int d, int 
     if (!out || N < 0 || B <= 0 || n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D) return MFCD_EINVAL;
     std::memset(out, 0, sizeof(*out));
     const TrainLayout L = train_layout(N, B, n, m, d);
-    const FormChoice fc = choose_form(!bf16_factors, L.resident, N > 0 ? N : 1, B, n, m, d);
+    const FormChoice fc = choose_form(!bf16_factors, L.resident, L.ev.tshift, N > 0 ? N : 1, B, n, m, d);
     if (fc.form < 0) return fc.form;
     out->form = fc.form;
     if (fc.form == 2) {
@@ -967,6 +989,54 @@ extern "C" int mfcd_train_steps_timed(float *U, float *V, float *mU, float *vU, 
     if (!kernel_us_host) return MFCD_EINVAL;
     return run_train_steps<float>(U, V, mU, vU, mV, vV, samples, N, B, step0, n, m, d, lr, beta1, beta2, eps,
                                   weight_decay, loss_per_step, workspace, workspace_bytes, stream, kernel_us_host);
+}
+
+namespace {
+struct TrainCall {
+    void *U, *V;
+    float *mU, *vU, *mV, *vV;
+    int bf16, B, n, m, d;
+    double lr, beta1, beta2, eps, wd;
+    void *workspace;
+    size_t workspace_bytes;
+};
+}  // namespace
+
+extern "C" int mfcd_train_call_prepare(void *U, void *V, float *mU, float *vU, float *mV, float *vV, int bf16_factors,
+                                       int B, int n, int m, int d, double lr, double beta1, double beta2, double eps,
+                                       double weight_decay, void *workspace, size_t workspace_bytes, void **handle_out)
+{
+    if (!handle_out) return MFCD_EINVAL;
+    *handle_out = nullptr;
+    if (int rc = check_common(U, V, n, m, d)) return rc;
+    if (!mU || !vU || !mV || !vV || B <= 0 || !workspace) return MFCD_EINVAL;
+    WsState *S = find_ws(workspace);
+    if (!S) return MFCD_ESTATE;
+    if (n != S->n || m != S->m || d != S->d) return MFCD_ESTATE;
+    if (workspace_bytes < S->L.total) return MFCD_EWORKSPACE;
+    *handle_out = new TrainCall{U, V, mU, vU, mV, vV, bf16_factors ? 1 : 0, B, n, m, d, lr, beta1, beta2, eps,
+                                weight_decay, workspace, workspace_bytes};
+    return 0;
+}
+
+extern "C" int mfcd_train_call_run(void *handle, const mfcd_sample *samples, int64_t N, int64_t step0,
+                                   float *loss_per_step, void *stream)
+{
+    const TrainCall *c = (const TrainCall *)handle;
+    if (!c) return MFCD_EINVAL;
+    if (c->bf16)
+        return run_train_steps<mfcd_bf16>((mfcd_bf16 *)c->U, (mfcd_bf16 *)c->V, c->mU, c->vU, c->mV, c->vV, samples, N,
+                                          c->B, step0, c->n, c->m, c->d, c->lr, c->beta1, c->beta2, c->eps, c->wd,
+                                          loss_per_step, c->workspace, c->workspace_bytes, stream, nullptr);
+    return run_train_steps<float>((float *)c->U, (float *)c->V, c->mU, c->vU, c->mV, c->vV, samples, N, c->B, step0,
+                                  c->n, c->m, c->d, c->lr, c->beta1, c->beta2, c->eps, c->wd, loss_per_step,
+                                  c->workspace, c->workspace_bytes, stream, nullptr);
+}
+
+extern "C" int mfcd_train_call_release(void *handle)
+{
+    delete (TrainCall *)handle;
+    return 0;
 }
 
 extern "C" int mfcd_batch_coefficients(const float *U, const float *V, const mfcd_sample *samples, int B, int n,

@@ -144,6 +144,7 @@ struct ResidentPlan {
     int lookahead;   // 0, 4 or 8: the instantiation the launch uses
     bool fast_math;
     bool bf16;       // bf16 factor tables
+    int tshift;      // look-ahead form: log2(steps per chunk of the per-wave event lists)
 };
 
 constexpr unsigned kSpinLimitDefault = 1u << 22;  // polls before a wave gives up (~seconds); sets status = 1
@@ -167,22 +168,35 @@ int set_uvt_wpe128(int v);   // uvt.hip
 int set_uvt_target_wgs(int v);   // uvt.hip
 int set_uvt_min_stages(int v);   // uvt.hip
 
-ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, bool bf16 = false);
+// ev_tshift: chunk length of the event lists the WORKSPACE was laid out for (ResidentEvents::tshift; 0 = no lists, the
+// look-ahead form is then not planned)
+ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, bool bf16 = false, int ev_tshift = -1);
 int resident_lookahead(int64_t N, int B, int n, int m);
 
+// Geometry of the per-wave event lists of the look-ahead form (resident_kernel.h) for tables of this shape and batch
+// size: a function of the shape alone (the smallest slice that fits, never of a tuning knob), so that a workspace
+// planned once serves every call.  tshift = 0: the lists do not apply (a wave would see a hit nearly every step).
+struct ResidentEvents {
+    int tshift;        // log2(steps per chunk), 4 .. 8
+    int waves;         // owner waves the arrays are laid out for
+    int rows_per_wave;
+};
+ResidentEvents resident_events(int B, int n, int m, int d, int num_cus);
+constexpr int kResidentEventCap = 64;          // entries per (wave, chunk) list = one per lane (resident_kernel.h)
+constexpr int kResidentEventLook = 8;          // deepest look-ahead window: boundary copies per chunk
+inline int64_t resident_event_chunks(int64_t K, int tshift) { return (K >> tshift) + 2; }
+
 // One kernel in front of a resident / local launch: pinned staging slot -> workspace, and (xs != nullptr) the
-// translated samples + touch strings of the resident form.
+// translated samples + (look > 0) the per-wave event lists of the resident form.
 int launch_train_prologue(const void *stage_host, const void *stage_host_devview, void *stage_dev, size_t stage_bytes,
-                          const mfcd_sample *samples, int64_t N, int B, int n, int m, int rows_per_wave, int KW,
-                          int want_touch, mfcd_sample *xs, unsigned *touch, hipStream_t st);
+                          const mfcd_sample *samples, int64_t N, int B, int n, int m, int rows_per_wave, int tshift,
+                          int look, int64_t nch_cap, mfcd_sample *xs, unsigned *ev_cnt, void *ev_ent, hipStream_t st);
 
 // cold_dev: device copy of ResidentCold (resident_kernel.h: table pointers, status word, spin limit, touch strings);
 // xs: the call's samples translated to virtual row ids
 int launch_resident_steps(const ResidentPlan &pl, const void *cold_dev, const mfcd_sample *xs, int64_t N, int B, int n,
                           int m, int d, const StepScalars *sc_dev, const AdamStatic &ac, unsigned long long *mailbox,
-                          unsigned tag_base, float *loss_terms, unsigned long long *dbg, int K, hipStream_t st);
-int resident_touch_words(int64_t K);    // dwords per string of the touch strings for a call of K steps
-size_t resident_touch_bytes(int64_t K); // bytes of the touch-string region for calls of up to K steps
+                          unsigned tag_base, void *loss_terms, unsigned long long *dbg, int K, hipStream_t st);
 constexpr int kResidentMaxWaves = 4096;   // 256 CUs x 16 waves: upper bound of ResidentPlan::NW (workspace sizing)
 
 }  // namespace mfcd_detail

@@ -31,6 +31,9 @@ SIGNATURES = {
     "mfcd_eval_batches_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfcd_train_steps_timed": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
                                [_vp, _vp, _sz, _vp, _vp]),
+    "mfcd_train_call_prepare": (_i32, [_vp] * 6 + [_i32] * 5 + [_dbl] * 5 + [_vp, _sz, ctypes.POINTER(ctypes.c_void_p)]),
+    "mfcd_train_call_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "mfcd_train_call_release": (_i32, [_vp]),
     "mfcd_batch_coefficients": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfcd_apply_step": (_i32, [_vp] * 8 + [_i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _sz, _vp]),
     "mfcd_dense_grad": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -93,7 +96,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if lib.mfcd_abi_version() != 2:
+        if lib.mfcd_abi_version() != 3:
             raise MfcdError("libmfcd_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -100,6 +100,40 @@ class AdamBinding:
 
     def refresh(self):
         self._ctx = None
+        self.drop_prepared()
+
+    # ---- prepared calls (include/mfcd.h: mfcd_train_call_*) ----
+    def prepared(self, ws, batch_size):
+        """Handle of a prepared call for this binding on planned workspace `ws` (a Workspace) and batch size, made on
+        first use and re-made when anything it binds has changed: the workspace buffer (re-plan), a hyper-parameter
+        (learning-rate schedules write param_groups between calls) or the tables (refresh())."""
+        g = self.group
+        key = (ws.buf.data_ptr(), batch_size, g["lr"], g["betas"], g["eps"], g["weight_decay"])
+        hit = getattr(self, "_prep", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        import ctypes
+        self.drop_prepared()
+        L = _lib.load()
+        ptrs, n, m, d, dev, dtype = self.call_context()
+        lr, b1, b2, eps, wd = self.hyper()
+        h = ctypes.c_void_p()
+        _lib.check(L.mfcd_train_call_prepare(*ptrs, int(dtype == torch.bfloat16), batch_size, n, m, d, lr, b1, b2, eps,
+                                             wd, ws.buf.data_ptr(), ws.buf.numel(), ctypes.byref(h)))
+        self._prep = (key, h, ws.buf)          # (the buffer is kept alive as long as the handle names it)
+        return h
+
+    def drop_prepared(self):
+        hit = getattr(self, "_prep", None)
+        if hit is not None:
+            self._prep = None
+            _lib.load().mfcd_train_call_release(hit[1])
+
+    def __del__(self):
+        try:
+            self.drop_prepared()
+        except Exception:
+            pass
 
 
 def generate_labels(triplets, X, scale=1.0, K=1, soft=False, seed=0, device=None):
@@ -344,18 +378,23 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None,
         return torch.empty(0, dtype=torch.float32, device=dev) if loss_out is None else loss_out[:0]
     if loss_out is None:
         loss_out = torch.empty(nsteps, dtype=torch.float32, device=dev)
-    ws = workspace_for(dev, (n, m, d)).ensure(N, batch_size, n, m, d, dev)
+    wso = workspace_for(dev, (n, m, d))
+    ws = wso.ensure(N, batch_size, n, m, d, dev)
+    if kernel_us is None:
+        # the prepared call: tables, shape, hyper-parameters and workspace were bound once; five scalars cross the boundary
+        if not samples_dev.is_contiguous():
+            raise _lib.MfcdError("the HIP hot path needs contiguous tensors")
+        code = L.mfcd_train_call_run(binding.prepared(wso, batch_size), samples_dev.data_ptr(), N, binding.step,
+                                     loss_out.data_ptr(), _lib.stream_ptr(dev))
+        if code:
+            _lib.check(code)
+        binding.advance(nsteps, defer_step)
+        return loss_out if loss_out.shape[0] == nsteps else loss_out[:nsteps]
     lr, b1, b2, eps, wd = binding.hyper()
     args = ptrs + (_lib.ptr(samples_dev), N, batch_size, binding.step, n, m, d, lr, b1, b2, eps, wd,
                    loss_out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
     if dtype == torch.bfloat16:
-        if kernel_us is not None:
-            raise NotImplementedError("the timed diagnostic twin exists for fp32 factors only")
-        _lib.check(L.mfcd_train_steps_bf16(*args))
-    elif kernel_us is None:
-        code = L.mfcd_train_steps(*args)
-        if code:
-            _lib.check(code)
+        raise NotImplementedError("the timed diagnostic twin exists for fp32 factors only")
     else:
         import ctypes
         out = (ctypes.c_float * 3)()
