@@ -203,7 +203,7 @@ __device__ __forceinline__ void event_append(unsigned *__restrict__ ev_cnt, uint
                                              const uint4 &e)
 {
     const unsigned slot = atomicAdd(ev_cnt + list, 1u);
-    if (slot < (unsigned)kEventCap) ev_ent[list * kEventCap + slot] = e;
+    if (slot < (unsigned)kEventCap - 1u) ev_ent[list * kEventCap + slot] = e;   // a usable list holds <= 63 entries
 }
 
 template <bool INLINE>

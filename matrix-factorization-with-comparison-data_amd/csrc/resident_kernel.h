@@ -7,6 +7,36 @@ namespace mfcd_detail {
 
 typedef unsigned long long u64;
 
+// Diagnostic build (-DMFCD_RES_STATS, tools/diag_resident_stats.py only): per-wave cycle / event accounting of the
+// look-ahead loop, written to dbg[8 + wave*8 ..]:
+//   0 whole step loop  1 event steps (everything between "k == next_evt" and the dense update)  2 granule polls that
+//   had to wait (from the first failed poll to success)  3 publish passes  4 hits | hits served from the one-step-ahead
+//   request << 20 | hits whose first poll succeeded << 40   5 failed polls  6 kernel start -> first step
+//   7 rows published | event steps << 32
+#ifdef MFCD_RES_STATS
+#define RS_NOW() ((u64)__builtin_amdgcn_s_memtime())
+#define RS_ADD(slot, val) rs_acc[slot] += (u64)(val)
+#else
+#define RS_NOW() ((u64)0)
+#define RS_ADD(slot, val) ((void)0)
+#endif
+
+// The per-step Adam scalars are written by the prologue kernel of the call and only read here: reading them through
+// the constant address space makes every such load a SCALAR load (s_load through the scalar cache, values in SGPRs,
+// lgkmcnt), whatever the kernel stores elsewhere.  As plain global loads they were vector loads whose vmcnt(0) wait at
+// the end of every step also drained the granule requests issued one step ahead.
+typedef const __attribute__((address_space(4))) float *ScalarTablePtr;
+__device__ __forceinline__ StepScalars load_step_scalars(const StepScalars *table, int k)
+{
+    const ScalarTablePtr f = (ScalarTablePtr)(table + k);
+    StepScalars s;
+    s.neg_step_size = f[0];
+    s.bc2_sqrt = f[1];
+    s.inv_bc2_sqrt = f[2];
+    s.pad = 0.0f;
+    return s;
+}
+
 
 __device__ __forceinline__ u64 pack_granule(unsigned tag, float v)
 {
@@ -72,7 +102,7 @@ __host__ __device__ inline RowMap make_row_map(int n, int m)
 //   word 2: the sample's label z (fp32 bits);  word 3: unused
 // A list that does not fit (a row that most batches name: popularity-sampled heads) makes its wave take the generic
 // publish-right-before-use loop for the whole launch; the granule protocol is the same, so the two kinds of wave mix.
-constexpr int kEventCap = 64;
+constexpr int kEventCap = 64;          // slots per list; a list that is USED holds at most kEventCap - 1 entries
 constexpr unsigned kEventNone = 0xFFFFFFF8u;   // sorts last, step 0x7FFFFF, no own role
 constexpr int kEventMaxLocalRows = 1024;
 
@@ -164,6 +194,10 @@ void resident_train_kernel(ResidentArgs a)
     auto elem_is_item = [&](int64_t e) { return make_row_map(a.n, a.m).is_item((int)(e / D)); };
     auto elem_offset = [&](int64_t e) { return (int64_t)make_row_map(a.n, a.m).table_row((int)(e / D)) * D + (e % D); };
 
+#ifdef MFCD_RES_STATS
+    u64 rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const u64 rs_t0 = RS_NOW();
+#endif
     // ---- load my slice of the state into registers ----
     float p[Q], m1[Q], m2[Q], gr[GRL ? 1 : Q];
     float *const lgr = lds_dyn + (threadIdx.x >> 6) * (GRL ? EW : 0);   // this wave's accumulators: element q*64 + lane
@@ -281,6 +315,8 @@ void resident_train_kernel(ResidentArgs a)
         // rows owned by other waves: their granules, polled until every tag is this step's
         unsigned spins = 0, limit = 0;
         bool have = pre;
+        [[maybe_unused]] u64 rs_w0 = 0;
+        RS_ADD(4, 1ull | (pre ? 1ull << 20 : 0ull));
         while (true) {
             bool ok = true;
 #pragma unroll
@@ -298,11 +334,19 @@ void resident_train_kernel(ResidentArgs a)
             }
             if (__all(ok)) break;
             have = false;
+#ifdef MFCD_RES_STATS
+            if (spins == 0) rs_w0 = RS_NOW();
+            RS_ADD(5, 1);
+#endif
             if (poll_failed(spins, limit)) {
                 give_up(step, pos, (own0 ? 1 : 0) | (own1 ? 2 : 0) | (own2 ? 4 : 0));
                 return false;
             }
         }
+#ifdef MFCD_RES_STATS
+        if (spins) RS_ADD(2, RS_NOW() - rs_w0);
+        else RS_ADD(4, 1ull << 40);
+#endif
 
         float acc = 0.0f;
 #pragma unroll
@@ -407,7 +451,7 @@ void resident_train_kernel(ResidentArgs a)
             const int64_t pos0 = (int64_t)k * a.B;
             const int Bk = batch_size(k);
             const float inv_batch = 1.0f / (float)Bk;
-            const StepScalars sc = a.sc[k];
+            const StepScalars sc = load_step_scalars(a.sc, k);
             if constexpr (!GRL) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
@@ -450,14 +494,15 @@ void resident_train_kernel(ResidentArgs a)
         bool fits = true;
         {
             const unsigned *cnt = a.cold->ev_cnt + (size_t)gws * (size_t)a.cold->nch_cap;
-            for (int c = lane; c < NCH; c += MFCD_WAVE) fits = fits && cnt[c] <= (unsigned)kEventCap;
+            for (int c = lane; c < NCH; c += MFCD_WAVE) fits = fits && cnt[c] < (unsigned)kEventCap;   // lane 63 stays a sentinel
             fits = __all(fits);
         }
         if (!__builtin_amdgcn_readfirstlane((int)fits)) {
             alive = generic_loop();
         } else {
-            // this lane's entry of the current chunk's list, sorted by word 0 (kEventNone past the end)
+            // this lane's entry of the current chunk's list, sorted by word 0 (kEventNone past the end; lane 63 always)
             unsigned ekey = kEventNone, erow = 0u;
+            int estep = 0x7FFFFF;                                  // ekey >> 9
             float ez = 0.0f;
             int chunk_end = 0;                                     // first step that is not in the current chunk
 
@@ -481,16 +526,15 @@ void resident_train_kernel(ResidentArgs a)
                 ekey = (unsigned)__builtin_amdgcn_ds_permute(dest, (int)key);
                 erow = (unsigned)__builtin_amdgcn_ds_permute(dest, (int)e.y);
                 ez = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest, (int)e.z));
+                estep = (int)(ekey >> 9);
                 const int ce = (c + 1) << tshift;
                 chunk_end = ce < a.K ? ce : a.K;
             };
-            // lanes whose entry's step is < x: a prefix of the sorted list
-            auto lt = [&](int x) -> u64 { return __ballot((int)(ekey >> 9) < x); };
-            // step of the first entry whose step is >= x (0x7FFFFF: none)
-            auto first_step_ge = [&](int x) -> int {
-                const int idx = __builtin_popcountll(lt(x));
-                return idx < 64 ? (int)((unsigned)__builtin_amdgcn_readlane((int)ekey, idx) >> 9) : 0x7FFFFF;
-            };
+            // The sorted list is walked with two cursors (scalars): hc = the first entry whose step is >= the current
+            // step (the next hit), pc = the first entry that has not entered the look-ahead window yet.  A list holds at
+            // most 63 entries, so lane 63 is always a sentinel and a cursor never leaves the wave.
+            auto step_at = [&](int i) -> int { return __builtin_amdgcn_readlane(estep, i); };
+            auto lanes_in = [](int lo, int hi) -> u64 { return ((1ull << hi) - 1ull) & ~((1ull << lo) - 1ull); };   // 0 <= lo, hi <= 63
             // lanes whose entry names my local row lr (in a role I own)
             auto rowmask = [&](int lr) -> u64 {
                 const bool t = ((ekey & 1u) && (int)(erow & 1023u) == lr) ||
@@ -499,82 +543,91 @@ void resident_train_kernel(ResidentArgs a)
                 return __ballot(t);
             };
 
-            // Publish pass.  The registers hold the state after step jbase (-1: the initial state).  Entry e (step ke,
+            // Publishing rule.  The registers hold the state after step jbase (-1: the initial state).  Entry e (step ke,
             // role r, my row lr) is due now iff no entry with a step in (jbase, ke) names lr, and
-            //   fresh  (after the update of a hit step / at the start): ke <= jbase + W and batch jbase named lr (its value
-            //          for ke could not be known earlier; at the start every row counts as just touched);
-            //   !fresh (before the hits and the update of step jbase + 1): ke == jbase + 1 + W — the entry has just
-            //          entered the window (a row that batch jbase + 1 names is in (jbase, ke) and waits for its update).
+            //   after the update of a hit step jbase:  ke <= jbase + W and batch jbase named lr (its value for ke could
+            //          not be known earlier); at the start (jbase = -1) every row counts as just touched;
+            //   before the hits and the update of step jbase + 1:  ke == jbase + 1 + W — the entry has just entered the
+            //          window (a row that batch jbase + 1 names lies in (jbase, ke) and waits for its update).
             // Every (entry, role) is published exactly once: by the step of its row's previous touch if that lies
             // within W steps, else W steps ahead.  The row is rolled forward over steps jbase+1 .. ke-1 (dense-only
             // updates, same arithmetic in the same order as the slice will see: identical bits).
-            auto publish_pass = [&](int jbase, bool fresh) {
-                const u64 lo = lt(jbase + 1);                      // steps <= jbase
-                u64 cand = fresh ? (lt(jbase + W + 1) & ~lo) : (lt(jbase + W + 2) & ~lt(jbase + W + 1));
-                if (cand == 0ull) return;
-                const u64 at_j = (fresh && jbase >= 0) ? (lo & ~lt(jbase)) : 0ull;
-                StepScalars scw[W];                                // scalars of steps jbase+1 .. jbase+W (table: K+1 entries)
-#pragma unroll
-                for (int b = 0; b < W; ++b) scw[b] = a.sc[(jbase + 1 + b) < a.K ? (jbase + 1 + b) : a.K];
-                while (cand) {
-                    const int l = __ffsll((long long)cand) - 1;
-                    cand &= cand - 1;
-                    const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)ekey, l);
-                    const unsigned row_l = (unsigned)__builtin_amdgcn_readlane((int)erow, l);
-                    const int ke = (int)(key_l >> 9);
-                    if (ke >= a.K) continue;                       // (boundary copies past the end of the call: none exist)
-                    const int tl = (int)((key_l >> 3) & 63u);
-                    const u64 between = lt(ke) & ~lo;              // steps in (jbase, ke)
+            // publish_entry: entry idx; entries [conf_lo, conf_hi) are the ones with a step in (jbase, ke), entries
+            // [touch_lo, touch_hi) those of step jbase (need_touch); scw[b] = scalars of step jbase + 1 + b.
+            auto publish_entry = [&](int idx, int jbase, int conf_lo, int conf_hi, int touch_lo, int touch_hi,
+                                     bool need_touch, const StepScalars (&scw)[W]) {
+                const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)ekey, idx);
+                const unsigned row_l = (unsigned)__builtin_amdgcn_readlane((int)erow, idx);
+                const int ke = (int)(key_l >> 9);
+                const int tl = (int)((key_l >> 3) & 63u);
 #pragma unroll 1
-                    for (int r = 0; r < 3; ++r) {
-                        if (!((key_l >> r) & 1u)) continue;
-                        const int lr = (int)((row_l >> (10 * r)) & 1023u);
+                for (int r = 0; r < 3; ++r) {
+                    if (!((key_l >> r) & 1u)) continue;
+                    const int lr = (int)((row_l >> (10 * r)) & 1023u);
+                    if (conf_lo < conf_hi || need_touch) {
                         const u64 rm = rowmask(lr);
-                        if (rm & between) continue;
-                        if (fresh && jbase >= 0 && !(rm & at_j)) continue;
-                        // roll the registers of my row lr forward over steps jbase+1 .. ke-1
-                        const int q0 = reg_of(lr);
-                        float pp[S], mm1[S], mm2[S];
+                        if (rm & lanes_in(conf_lo, conf_hi)) continue;
+                        if (need_touch && !(rm & lanes_in(touch_lo, touch_hi))) continue;
+                    }
+                    // roll the registers of my row lr forward over steps jbase+1 .. ke-1
+                    const int q0 = reg_of(lr);
+                    float pp[S], mm1[S], mm2[S];
 #pragma unroll
-                        for (int s2 = 0; s2 < S; ++s2) pp[s2] = mm1[s2] = mm2[s2] = 0.0f;
+                    for (int s2 = 0; s2 < S; ++s2) pp[s2] = mm1[s2] = mm2[s2] = 0.0f;
 #pragma unroll
-                        for (int q = 0; q < Q; ++q) {
-                            if (q >= q0 && q < q0 + S) {
-                                const int s2 = D >= 64 ? (q * 64 % D) / 64 : 0;
-                                pp[s2] = p[q];
-                                mm1[s2] = m1[q];
-                                mm2[s2] = m2[q];
-                            }
-                        }
-                        const int nroll = ke - 1 - jbase;          // 0 .. W
-#pragma unroll
-                        for (int b = 0; b < W; ++b) {
-                            if (b < nroll) {
-#pragma unroll
-                                for (int s2 = 0; s2 < S; ++s2) {
-                                    adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b]);
-                                    pp[s2] = post(pp[s2]);
-                                }
-                            }
-                        }
-                        u64 *dst = a.mailbox + (((int64_t)ke * a.B + tl) * 3 + r) * D;
-                        const unsigned tag = a.tag_base + (unsigned)ke + 1u;
-                        if constexpr (D >= 64) {
-#pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) store_granule(dst + s2 * 64 + lane, tag, pp[s2]);
-                        } else {
-                            if (lane / D == lr % RPR) store_granule(dst + lcol, tag, pp[0]);
+                    for (int q = 0; q < Q; ++q) {
+                        if (q >= q0 && q < q0 + S) {
+                            const int s2 = D >= 64 ? (q * 64 % D) / 64 : 0;
+                            pp[s2] = p[q];
+                            mm1[s2] = m1[q];
+                            mm2[s2] = m2[q];
                         }
                     }
+                    const int nroll = ke - 1 - jbase;              // 0 .. W
+#pragma unroll
+                    for (int b = 0; b < W; ++b) {
+                        if (b < nroll) {
+#pragma unroll
+                            for (int s2 = 0; s2 < S; ++s2) {
+                                adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b]);
+                                pp[s2] = post(pp[s2]);
+                            }
+                        }
+                    }
+                    u64 *dst = a.mailbox + (((int64_t)ke * a.B + tl) * 3 + r) * D;
+                    const unsigned tag = a.tag_base + (unsigned)ke + 1u;
+                    if constexpr (D >= 64) {
+#pragma unroll
+                        for (int s2 = 0; s2 < S; ++s2) store_granule(dst + s2 * 64 + lane, tag, pp[s2]);
+                    } else {
+                        if (lane / D == lr % RPR) store_granule(dst + lcol, tag, pp[0]);
+                    }
+                    RS_ADD(7, 1);
                 }
             };
-
-            // request, one step ahead, the foreign granules of the FIRST entry of step k1 (if there is one)
-            auto prefetch_for = [&](int k1) {
-                const int idx = __builtin_popcountll(lt(k1));
-                if (idx >= 64) return;
+            auto load_window_scalars = [&](int jbase, StepScalars (&scw)[W]) {   // steps jbase+1 .. jbase+W (table: K+1 entries)
+#pragma unroll
+                for (int b = 0; b < W; ++b) scw[b] = load_step_scalars(a.sc, (jbase + 1 + b) < a.K ? (jbase + 1 + b) : a.K);
+            };
+            // entries [lo, hi) (steps in (jbase, jbase + W]) from the state after step jbase; the rows must have been
+            // named by the entries [touch_lo, touch_hi) of step jbase (jbase >= 0)
+            auto publish_fresh = [&](int jbase, int lo, int hi, int touch_lo, int touch_hi) {
+                if (lo >= hi) return;
+                [[maybe_unused]] const u64 rs_p0 = RS_NOW();
+                StepScalars scw[W];
+                load_window_scalars(jbase, scw);
+                int g0 = lo, gstep = step_at(lo);                  // first entry of the current entry's step
+                for (int idx = lo; idx < hi; ++idx) {
+                    const int st = step_at(idx);
+                    if (st != gstep) { g0 = idx; gstep = st; }
+                    publish_entry(idx, jbase, lo, g0, touch_lo, touch_hi, jbase >= 0, scw);
+                }
+                RS_ADD(3, RS_NOW() - rs_p0);
+            };
+            // request, one step ahead, the foreign granules of entry idx
+            auto prefetch_entry = [&](int idx) {
                 const unsigned key1 = (unsigned)__builtin_amdgcn_readlane((int)ekey, idx);
-                if ((int)(key1 >> 9) != k1) return;
+                const int k1 = (int)(key1 >> 9);
                 const int tl = (int)((key1 >> 3) & 63u);
                 const u64 *slot = a.mailbox + ((int64_t)k1 * a.B + tl) * 3 * D;
 #pragma unroll
@@ -588,48 +641,71 @@ void resident_train_kernel(ResidentArgs a)
                 }
                 pf_key = key1;
             };
-            // the next step at which this wave has anything to do besides its dense update, seen from step k (> k)
+
+            load_chunk(0);
+            int hc = 0, pc = __builtin_popcountll(__ballot(estep < W));
+            publish_fresh(-1, 0, pc, 0, 0);                        // first uses within the first W steps, from the initial state
+            int nh = step_at(0), np = step_at(pc);
+            if (nh == 0) prefetch_entry(0);
+            // the next step at which this wave has anything to do besides its dense update: a hit (be there one step
+            // early for the granule request), an entry entering the window, the end of the chunk
             auto next_event = [&](int k) -> int {
-                const int s_h = first_step_ge(k + 1);              // next hit: be there one step early (granule request)
-                const int ch = s_h - 1 > k ? s_h - 1 : k + 1;
-                const int cp = first_step_ge(k + W + 1) - W;       // next entry to enter the window
+                const int ch = nh - 1 > k ? nh - 1 : k + 1;
+                const int cp = np - W;
                 const int e = ch < cp ? ch : cp;
                 return e < chunk_end ? e : chunk_end;
             };
-
-            load_chunk(0);
-            publish_pass(-1, true);
-            prefetch_for(0);
             int next_evt = next_event(-1);
 
-            StepScalars sc_cur = a.sc[0];
-            const StepScalars *sc_ptr = a.sc + 1;      // running pointer: the table holds K+1 entries (host pads one)
+            StepScalars sc_cur = load_step_scalars(a.sc, 0);
             int chunk = 0;
+#ifdef MFCD_RES_STATS
+            const u64 rs_l0 = RS_NOW();
+            rs_acc[6] = rs_l0 - rs_t0;
+#endif
             for (int k = 0; k < a.K; ++k) {
-                const StepScalars sc_next = *sc_ptr++;
+                const StepScalars sc_next = load_step_scalars(a.sc, k + 1);   // (the table holds K+1 entries)
                 if constexpr (!GRL) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
                 }
                 bool hit = false;
+                int h0 = 0;
                 if (__builtin_expect(k == next_evt, 0)) {
                     // a wave with an event is on somebody's critical chain, the waves on the common path have slack:
                     // it issues ahead of them until its step is done
                     __builtin_amdgcn_s_setprio(3);
-                    if (k == chunk_end) load_chunk(++chunk);
-                    publish_pass(k - 1, false);                    // entries that enter the window: step k + W
-                    u64 H = lt(k + 1) & ~lt(k);                    // my hits of this step, in batch order
-                    if (H) {
+                    [[maybe_unused]] const u64 rs_e0 = RS_NOW();
+                    RS_ADD(7, 1ull << 32);
+                    if (k == chunk_end) {
+                        load_chunk(++chunk);
+                        hc = 0;
+                        nh = step_at(0);
+                        pc = __builtin_popcountll(__ballot(estep < k + W));   // (earlier steps entered the window in the last chunk)
+                        np = step_at(pc);
+                    }
+                    if (np == k + W) {                             // entries that enter the window now
+                        [[maybe_unused]] const u64 rs_p0 = RS_NOW();
+                        StepScalars scw[W];
+                        load_window_scalars(k - 1, scw);
+                        const int g0 = pc;
+                        do {
+                            publish_entry(pc, k - 1, hc, g0, 0, 0, false, scw);
+                            ++pc;
+                            np = step_at(pc);
+                        } while (np == k + W);
+                        RS_ADD(3, RS_NOW() - rs_p0);
+                    }
+                    h0 = hc;
+                    if (nh == k) {                                 // my hits of this step, in batch order
                         hit = true;
                         const int bk = (N32 - k * a.B) < a.B ? (N32 - k * a.B) : a.B;
                         const float inv_batch = 1.0f / (float)bk;
                         const unsigned tag = a.tag_base + (unsigned)k + 1u;
-                        while (H) {
-                            const int l = __ffsll((long long)H) - 1;
-                            H &= H - 1;
-                            const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)ekey, l);
-                            const unsigned row_l = (unsigned)__builtin_amdgcn_readlane((int)erow, l);
-                            const float z_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ez), l));
+                        do {
+                            const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)ekey, hc);
+                            const unsigned row_l = (unsigned)__builtin_amdgcn_readlane((int)erow, hc);
+                            const float z_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ez), hc));
                             const bool pre = key_l == pf_key;
                             // the abort decision is wave-uniform; saying so keeps the step loop free of exec-mask bookkeeping
                             const bool ok = process_hit((bool)(key_l & 1u), (bool)(key_l & 2u), (bool)(key_l & 4u),
@@ -637,22 +713,30 @@ void resident_train_kernel(ResidentArgs a)
                                                         (int)((row_l >> 20) & 1023u), z_l,
                                                         (int64_t)k * a.B + (int)((key_l >> 3) & 63u), tag, inv_batch, pre, k);
                             if (__builtin_amdgcn_readfirstlane((int)!ok)) { alive = false; break; }
-                        }
+                            ++hc;
+                            nh = step_at(hc);
+                        } while (nh == k);
                         pf_key = kEventNone;
                         if (!alive) break;
                     }
-                    prefetch_for(k + 1);
+                    if (nh == k + 1) prefetch_entry(hc);
                     next_evt = next_event(k);
                     if (!hit) __builtin_amdgcn_s_setprio(0);
+                    RS_ADD(1, RS_NOW() - rs_e0);
                 }
                 step_update(hit, sc_cur);
                 if (__builtin_expect(hit, 0)) {
-                    publish_pass(k, true);                         // rows batch k touched: their next use, if within W steps
+                    publish_fresh(k, hc, pc, h0, hc);              // rows batch k touched: their next use, if within W steps
                     __builtin_amdgcn_s_setprio(0);
                 }
                 sc_cur = sc_next;
             }
             __builtin_amdgcn_s_setprio(0);
+#ifdef MFCD_RES_STATS
+            rs_acc[0] = RS_NOW() - rs_l0;
+            if (lane == 0 && a.dbg)
+                for (int x = 0; x < 8; ++x) a.dbg[8 + (int64_t)gw * 8 + x] = rs_acc[x];
+#endif
         }
 
         // ---- batch means, inside the launch: wave w forms the mean BCE of steps w, w + NW, ... from the tagged sigmoid
