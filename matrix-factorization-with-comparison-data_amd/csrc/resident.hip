@@ -85,7 +85,7 @@ int resident_lookahead(int64_t N, int B, int n, int m)
     // tiny tables: a batch touches so large a share of the rows that nearly every row recurs inside the window
     // and each publish takes the deferred (slow) path; publishing right before use is faster there
     if (g_tune.lookahead < 0 && (int64_t)(n + m) < (int64_t)96 * B) la = 0;
-    return la >= 8 ? 8 : (la > 0 ? 4 : 0);
+    return la > 16 ? 16 : (la < 0 ? 0 : la);
 }
 
 // Workgroups of the instantiation (d, Q, look, fast) one CU holds at once, as the runtime reports it for the actual
@@ -137,7 +137,9 @@ ResidentEvents resident_events(int B, int n, int m, int d, int num_cus)
     // expected list entries per wave and step for uniformly drawn rows; a chunk of T steps (plus the boundary copies of
     // the deepest window) should average <= 20 of the 64 slots, so that an overflow is a property of the data (a row
     // most batches name), not of chance: P[Poisson(20) > 64] ~ 1e-14
-    const double h = 3.0 * B * ev.rows_per_wave / (double)(n + m);
+    // (priced for slices of TWICE the smallest size: the plan may take the next slice size up — waves-per-CU knob,
+    // occupancy of the actual code object — on the same workspace)
+    const double h = 2.0 * 3.0 * B * ev.rows_per_wave / (double)(n + m);
     for (int ts = 8; ts >= 4; --ts)
         if (h * ((1 << ts) + kResidentEventLook) <= 20.0) {
             ev.tshift = ts;
@@ -156,7 +158,6 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, b
     const int wpc = g_tune.resident_wpc > 0 ? g_tune.resident_wpc : 16;
     int look = resident_lookahead(N, B, n, m);
     const bool fast = g_resident_math != 0;
-    if (bf16 && look >= 8) look = 4;
     if (ev_tshift < 0) ev_tshift = resident_events(B, n, m, d, num_cus).tshift;
     if (ev_tshift == 0) look = 0;          // no event lists for this shape: publish right before use
     static const int kQ[5] = {1, 2, 4, 16, 32};

@@ -21,17 +21,15 @@ bool with_kernel(int look, int fast, int bf16, F fn)
 {
     if constexpr ((64 * Q) % D == 0) {
         using mfcd_detail::resident_train_kernel;
+        // the look-ahead depth is a launch argument (ResidentArgs::lookahead): LOOK only says "look-ahead form"
         if (bf16) {
-            if (look >= 8) return false;
             if (look > 0 && fast) fn(resident_train_kernel<D, Q, 4, true, true>);
             else if (look > 0) fn(resident_train_kernel<D, Q, 4, false, true>);
             else if (fast) fn(resident_train_kernel<D, Q, 0, true, true>);
             else fn(resident_train_kernel<D, Q, 0, false, true>);
             return true;
         }
-        if (look >= 8 && fast) fn(resident_train_kernel<D, Q, 8, true, false>);
-        else if (look >= 8) fn(resident_train_kernel<D, Q, 8, false, false>);
-        else if (look > 0 && fast) fn(resident_train_kernel<D, Q, 4, true, false>);
+        if (look > 0 && fast) fn(resident_train_kernel<D, Q, 4, true, false>);
         else if (look > 0) fn(resident_train_kernel<D, Q, 4, false, false>);
         else if (fast) fn(resident_train_kernel<D, Q, 0, true, false>);
         else fn(resident_train_kernel<D, Q, 0, false, false>);

@@ -7,11 +7,16 @@ namespace mfcd_detail {
 
 typedef unsigned long long u64;
 
+// Every lambda of the kernel must be inlined: a call would materialise its closure — references to the slice registers,
+// the list registers, the kernel arguments — in scratch memory and turn the step loop into a walk over private memory
+// (seen once: 0.64 -> 2.8 us per step when one lambda acquired a second call site).
+#define MFCD_LAMBDA_INLINE __attribute__((always_inline))
+
 // Diagnostic build (-DMFCD_RES_STATS, tools/diag_resident_stats.py only): per-wave cycle / event accounting of the
 // look-ahead loop, written to dbg[8 + wave*8 ..]:
 //   0 whole step loop  1 event steps (everything between "k == next_evt" and the dense update)  2 granule polls that
 //   had to wait (from the first failed poll to success)  3 publish passes  4 hits | hits served from the one-step-ahead
-//   request << 20 | hits whose first poll succeeded << 40   5 failed polls  6 kernel start -> first step
+//   request << 20 | hits whose first poll succeeded << 40   5 failed polls | XCC_ID << 32  6 kernel start -> first step | HW_ID << 32
 //   7 rows published | event steps << 32
 #ifdef MFCD_RES_STATS
 #define RS_NOW() ((u64)__builtin_amdgcn_s_memtime())
@@ -191,8 +196,8 @@ void resident_train_kernel(ResidentArgs a)
     const int Rhi = (int)(eend / D);  // my rows are VIRTUAL row ids [Rlo, Rhi)
     const int lcol = lane & (D - 1);  // column of my lane when D < 64
     // element e of the virtual table -> table and address offset inside U or V (kernel start and end only)
-    auto elem_is_item = [&](int64_t e) { return make_row_map(a.n, a.m).is_item((int)(e / D)); };
-    auto elem_offset = [&](int64_t e) { return (int64_t)make_row_map(a.n, a.m).table_row((int)(e / D)) * D + (e % D); };
+    auto elem_is_item = [&](int64_t e) MFCD_LAMBDA_INLINE { return make_row_map(a.n, a.m).is_item((int)(e / D)); };
+    auto elem_offset = [&](int64_t e) MFCD_LAMBDA_INLINE { return (int64_t)make_row_map(a.n, a.m).table_row((int)(e / D)) * D + (e % D); };
 
 #ifdef MFCD_RES_STATS
     u64 rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -201,7 +206,7 @@ void resident_train_kernel(ResidentArgs a)
     // ---- load my slice of the state into registers ----
     float p[Q], m1[Q], m2[Q], gr[GRL ? 1 : Q];
     float *const lgr = lds_dyn + (threadIdx.x >> 6) * (GRL ? EW : 0);   // this wave's accumulators: element q*64 + lane
-    auto post = [](float x) {   // the rounding point of bf16 factor storage: once per update
+    auto post = [](float x) MFCD_LAMBDA_INLINE {   // the rounding point of bf16 factor storage: once per update
         if constexpr (BF16) return (float)(mfcd_bf16)x;
         else return x;
     };
@@ -220,11 +225,11 @@ void resident_train_kernel(ResidentArgs a)
         }
     }
 
-    auto batch_size = [&](int step) {
+    auto batch_size = [&](int step) MFCD_LAMBDA_INLINE {
         const int64_t pos0 = (int64_t)step * a.B;
         return (int)((a.N - pos0) < a.B ? (a.N - pos0) : a.B);
     };
-    auto scan = [&](const mfcd_sample &s, int Bk, int base) {
+    auto scan = [&](const mfcd_sample &s, int Bk, int base) MFCD_LAMBDA_INLINE {
         const bool valid = base + lane < Bk;
         const int ru = s.u, ri = s.i, rj = s.j;   // virtual ids
         Masks M;
@@ -234,10 +239,10 @@ void resident_train_kernel(ResidentArgs a)
         return M;
     };
     // first register of my LOCAL row lr (virtual row Rlo + lr): wave-uniform
-    auto reg_of = [&](int lr) { return D >= 64 ? lr * S : lr / RPR; };
+    auto reg_of = [&](int lr) MFCD_LAMBDA_INLINE { return D >= 64 ? lr * S : lr / RPR; };
 
     // a bounded wait expired (or somebody else's did): make it known and remember who gave up first
-    auto give_up = [&](int step, int64_t pos, int what) {
+    auto give_up = [&](int step, int64_t pos, int what) MFCD_LAMBDA_INLINE {
         int *const status = a.cold->status;
         if (lane == 0) {
             if (__hip_atomic_exchange(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && a.dbg) {
@@ -246,7 +251,7 @@ void resident_train_kernel(ResidentArgs a)
         }
     };
     // one failed poll: returns true when the wave must give up (limit reached, or the abort word is set)
-    auto poll_failed = [&](unsigned &spins, unsigned &limit) -> bool {
+    auto poll_failed = [&](unsigned &spins, unsigned &limit) MFCD_LAMBDA_INLINE -> bool {
         if (spins == 0) limit = (unsigned)a.cold->spin_limit;   // first failed poll: the limit lives behind the cold pointer
         ++spins;
         if (spins > limit || (spins & 255u) == 0) {   // rare
@@ -258,7 +263,7 @@ void resident_train_kernel(ResidentArgs a)
     };
 
     // write my local row lr as tagged granules into mailbox slot (pos*3 + role)
-    auto store_row = [&](int lr, int64_t slot, unsigned tag) {
+    auto store_row = [&](int lr, int64_t slot, unsigned tag) MFCD_LAMBDA_INLINE {
         u64 *dst = a.mailbox + slot * D;
         const int q0 = reg_of(lr);
 #pragma unroll
@@ -286,7 +291,7 @@ void resident_train_kernel(ResidentArgs a)
     // step's tag.  pre: the foreign granules were requested a step ahead and sit in pf.  Returns false when a bounded
     // wait expired.
     auto process_hit = [&](bool own0, bool own1, bool own2, int lr0, int lr1, int lr2, float zz, int64_t pos,
-                           unsigned tag, float inv_batch, bool pre, int step) -> bool {
+                           unsigned tag, float inv_batch, bool pre, int step) MFCD_LAMBDA_INLINE -> bool {
         const bool own[3] = {own0, own1, own2};
         const int lrs[3] = {lr0, lr1, lr2};
         const u64 *slot = a.mailbox + pos * 3 * D;
@@ -342,6 +347,26 @@ void resident_train_kernel(ResidentArgs a)
                 give_up(step, pos, (own0 ? 1 : 0) | (own1 ? 2 : 0) | (own2 ? 4 : 0));
                 return false;
             }
+#ifdef MFCD_EXP_SLEEP
+            __builtin_amdgcn_s_sleep(MFCD_EXP_SLEEP);   // timing experiment (tools/): back off between failed polls
+#endif
+#ifdef MFCD_EXP_POLL1
+            // timing experiment (tools/): after a failed poll watch ONE granule per foreign row (8 bytes instead of 8 D)
+            // until its tag is this step's, then read the rows
+            while (true) {
+                bool ok1 = true;
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        if (!own[r]) ok1 = ok1 && ((unsigned)(load_granule(slot + (int64_t)r * D) >> 32) == tag);
+                }
+                if (__builtin_amdgcn_readfirstlane((int)ok1)) break;
+                if (poll_failed(spins, limit)) {
+                    give_up(step, pos, 16);
+                    return false;
+                }
+            }
+#endif
         }
 #ifdef MFCD_RES_STATS
         if (spins) RS_ADD(2, RS_NOW() - rs_w0);
@@ -398,7 +423,7 @@ void resident_train_kernel(ResidentArgs a)
     };
 
     // dense Adam over the slice for one step; `hit`: this wave accumulated row gradients in this step (wave-uniform)
-    auto step_update = [&](bool hit, const StepScalars &sc) {
+    auto step_update = [&](bool hit, const StepScalars &sc) MFCD_LAMBDA_INLINE {
         if constexpr (GRL) {
             if (hit) {
 #pragma unroll
@@ -428,8 +453,8 @@ void resident_train_kernel(ResidentArgs a)
     // ================= generic loop (any B): chunked scan, rows published right before their use =================
     // The whole launch of the LOOK = 0 instantiations, and the whole launch of a single WAVE of the look-ahead form whose
     // event list did not fit.  Returns false when a bounded wait expired.
-    auto generic_loop = [&]() -> bool {
-        auto publish = [&](int step) {
+    auto generic_loop = [&]() MFCD_LAMBDA_INLINE -> bool {
+        auto publish = [&](int step) MFCD_LAMBDA_INLINE {
             const int64_t pos0 = (int64_t)step * a.B;
             const int Bk = batch_size(step);
             for (int base = 0; base < Bk; base += MFCD_WAVE) {
@@ -484,7 +509,8 @@ void resident_train_kernel(ResidentArgs a)
 
     if constexpr (LOOK > 0) {
         // ================= B <= 64: look-ahead publishing driven by the wave's event list =================
-        constexpr int W = LOOK;
+        // depth of the look-ahead window: a launch argument (<= the boundary copies the lists were built with)
+        const int W = __builtin_amdgcn_readfirstlane(a.lookahead);
         const int N32 = (int)a.N;                                  // host guarantees N + 64*(W+2) < 2^31
         const int gws = __builtin_amdgcn_readfirstlane(gw);
         const int tshift = (int)a.cold->tshift;
@@ -506,10 +532,8 @@ void resident_train_kernel(ResidentArgs a)
             float ez = 0.0f;
             int chunk_end = 0;                                     // first step that is not in the current chunk
 
-            auto load_chunk = [&](int c) {
-                // (pointers re-derived from fresh scalar loads: nothing stays live across the step loop for them)
+            auto load_chunk = [&](int c) MFCD_LAMBDA_INLINE {
                 const ResidentCold *cz = a.cold;
-                asm volatile("" : "+s"(cz));
                 const size_t li = (size_t)gws * (size_t)cz->nch_cap + (size_t)c;
                 const uint4 e = cz->ev_ent[li * kEventCap + lane];   // past the count: stale bytes, masked below
                 const unsigned n_raw = cz->ev_cnt[li];
@@ -533,10 +557,10 @@ void resident_train_kernel(ResidentArgs a)
             // The sorted list is walked with two cursors (scalars): hc = the first entry whose step is >= the current
             // step (the next hit), pc = the first entry that has not entered the look-ahead window yet.  A list holds at
             // most 63 entries, so lane 63 is always a sentinel and a cursor never leaves the wave.
-            auto step_at = [&](int i) -> int { return __builtin_amdgcn_readlane(estep, i); };
-            auto lanes_in = [](int lo, int hi) -> u64 { return ((1ull << hi) - 1ull) & ~((1ull << lo) - 1ull); };   // 0 <= lo, hi <= 63
+            auto step_at = [&](int i) MFCD_LAMBDA_INLINE -> int { return __builtin_amdgcn_readlane(estep, i); };
+            auto lanes_in = [](int lo, int hi) MFCD_LAMBDA_INLINE -> u64 { return ((1ull << hi) - 1ull) & ~((1ull << lo) - 1ull); };   // 0 <= lo, hi <= 63
             // lanes whose entry names my local row lr (in a role I own)
-            auto rowmask = [&](int lr) -> u64 {
+            auto rowmask = [&](int lr) MFCD_LAMBDA_INLINE -> u64 {
                 const bool t = ((ekey & 1u) && (int)(erow & 1023u) == lr) ||
                                ((ekey & 2u) && (int)((erow >> 10) & 1023u) == lr) ||
                                ((ekey & 4u) && (int)((erow >> 20) & 1023u) == lr);
@@ -553,9 +577,9 @@ void resident_train_kernel(ResidentArgs a)
             // within W steps, else W steps ahead.  The row is rolled forward over steps jbase+1 .. ke-1 (dense-only
             // updates, same arithmetic in the same order as the slice will see: identical bits).
             // publish_entry: entry idx; entries [conf_lo, conf_hi) are the ones with a step in (jbase, ke), entries
-            // [touch_lo, touch_hi) those of step jbase (need_touch); scw[b] = scalars of step jbase + 1 + b.
+            // [touch_lo, touch_hi) those of step jbase (need_touch).
             auto publish_entry = [&](int idx, int jbase, int conf_lo, int conf_hi, int touch_lo, int touch_hi,
-                                     bool need_touch, const StepScalars (&scw)[W]) {
+                                     bool need_touch) MFCD_LAMBDA_INLINE {
                 const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)ekey, idx);
                 const unsigned row_l = (unsigned)__builtin_amdgcn_readlane((int)erow, idx);
                 const int ke = (int)(key_l >> 9);
@@ -569,7 +593,8 @@ void resident_train_kernel(ResidentArgs a)
                         if (rm & lanes_in(conf_lo, conf_hi)) continue;
                         if (need_touch && !(rm & lanes_in(touch_lo, touch_hi))) continue;
                     }
-                    // roll the registers of my row lr forward over steps jbase+1 .. ke-1
+                    // roll the registers of my row lr forward over steps jbase+1 .. ke-1; the scalars of step b+1 are
+                    // requested (scalar cache) before step b is computed
                     const int q0 = reg_of(lr);
                     float pp[S], mm1[S], mm2[S];
 #pragma unroll
@@ -583,16 +608,16 @@ void resident_train_kernel(ResidentArgs a)
                             mm2[s2] = m2[q];
                         }
                     }
-                    const int nroll = ke - 1 - jbase;              // 0 .. W
+                    StepScalars scb = load_step_scalars(a.sc, jbase + 1);          // (the table holds K+1 entries; ke <= K-1)
+#pragma unroll 1
+                    for (int st = jbase + 1; st < ke; ++st) {
+                        const StepScalars scn = load_step_scalars(a.sc, st + 1);
 #pragma unroll
-                    for (int b = 0; b < W; ++b) {
-                        if (b < nroll) {
-#pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2) {
-                                adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scw[b]);
-                                pp[s2] = post(pp[s2]);
-                            }
+                        for (int s2 = 0; s2 < S; ++s2) {
+                            adam_update_t<FAST>(pp[s2], mm1[s2], mm2[s2], 0.0f, a.ac, scb);
+                            pp[s2] = post(pp[s2]);
                         }
+                        scb = scn;
                     }
                     u64 *dst = a.mailbox + (((int64_t)ke * a.B + tl) * 3 + r) * D;
                     const unsigned tag = a.tag_base + (unsigned)ke + 1u;
@@ -605,27 +630,21 @@ void resident_train_kernel(ResidentArgs a)
                     RS_ADD(7, 1);
                 }
             };
-            auto load_window_scalars = [&](int jbase, StepScalars (&scw)[W]) {   // steps jbase+1 .. jbase+W (table: K+1 entries)
-#pragma unroll
-                for (int b = 0; b < W; ++b) scw[b] = load_step_scalars(a.sc, (jbase + 1 + b) < a.K ? (jbase + 1 + b) : a.K);
-            };
             // entries [lo, hi) (steps in (jbase, jbase + W]) from the state after step jbase; the rows must have been
             // named by the entries [touch_lo, touch_hi) of step jbase (jbase >= 0)
-            auto publish_fresh = [&](int jbase, int lo, int hi, int touch_lo, int touch_hi) {
+            auto publish_fresh = [&](int jbase, int lo, int hi, int touch_lo, int touch_hi) MFCD_LAMBDA_INLINE {
                 if (lo >= hi) return;
                 [[maybe_unused]] const u64 rs_p0 = RS_NOW();
-                StepScalars scw[W];
-                load_window_scalars(jbase, scw);
                 int g0 = lo, gstep = step_at(lo);                  // first entry of the current entry's step
                 for (int idx = lo; idx < hi; ++idx) {
                     const int st = step_at(idx);
                     if (st != gstep) { g0 = idx; gstep = st; }
-                    publish_entry(idx, jbase, lo, g0, touch_lo, touch_hi, jbase >= 0, scw);
+                    publish_entry(idx, jbase, lo, g0, touch_lo, touch_hi, jbase >= 0);
                 }
                 RS_ADD(3, RS_NOW() - rs_p0);
             };
             // request, one step ahead, the foreign granules of entry idx
-            auto prefetch_entry = [&](int idx) {
+            auto prefetch_entry = [&](int idx) MFCD_LAMBDA_INLINE {
                 const unsigned key1 = (unsigned)__builtin_amdgcn_readlane((int)ekey, idx);
                 const int k1 = (int)(key1 >> 9);
                 const int tl = (int)((key1 >> 3) & 63u);
@@ -646,32 +665,71 @@ void resident_train_kernel(ResidentArgs a)
             int hc = 0, pc = __builtin_popcountll(__ballot(estep < W));
             publish_fresh(-1, 0, pc, 0, 0);                        // first uses within the first W steps, from the initial state
             int nh = step_at(0), np = step_at(pc);
+#ifndef MFCD_EXP_NOPF
             if (nh == 0) prefetch_entry(0);
+#endif
             // the next step at which this wave has anything to do besides its dense update: a hit (be there one step
             // early for the granule request), an entry entering the window, the end of the chunk
-            auto next_event = [&](int k) -> int {
+            auto next_event = [&](int k) MFCD_LAMBDA_INLINE -> int {
+#ifdef MFCD_EXP_NOPF
+                const int ch = nh;                                 // timing experiment (tools/): no request one step ahead
+#else
                 const int ch = nh - 1 > k ? nh - 1 : k + 1;
+#endif
                 const int cp = np - W;
                 const int e = ch < cp ? ch : cp;
                 return e < chunk_end ? e : chunk_end;
             };
             int next_evt = next_event(-1);
 
-            StepScalars sc_cur = load_step_scalars(a.sc, 0);
+            // The step loop is cut at this wave's events: between two of them the wave runs QUIET steps — scalars of the
+            // next step requested, dense update with a literal zero gradient, counter — in a loop of its own with no
+            // flag, no gradient register and no event test inside (every instruction of this loop is paid by all
+            // waves at every step: the SIMDs' issue slots, not any wave's latency, bound the launch).
+            ScalarTablePtr scp = (ScalarTablePtr)a.sc;             // the table holds K+1 entries (host pads one)
+            auto load_scalars_at = [&](ScalarTablePtr f) MFCD_LAMBDA_INLINE {
+                StepScalars x;
+                x.neg_step_size = f[0];
+                x.bc2_sqrt = f[1];
+                x.inv_bc2_sqrt = f[2];
+                x.pad = 0.0f;
+                return x;
+            };
+            StepScalars sc_cur = load_scalars_at(scp);
             int chunk = 0;
 #ifdef MFCD_RES_STATS
             const u64 rs_l0 = RS_NOW();
             rs_acc[6] = rs_l0 - rs_t0;
 #endif
-            for (int k = 0; k < a.K; ++k) {
-                const StepScalars sc_next = load_step_scalars(a.sc, k + 1);   // (the table holds K+1 entries)
+            int k = 0;
+            while (true) {
+                const int kq = next_evt < a.K ? next_evt : a.K;
+                while (k < kq) {                                   // quiet steps
+                    scp += 4;
+                    const StepScalars sc_next = load_scalars_at(scp);
+                    if constexpr (GRL) {
+                        step_update(false, sc_cur);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            adam_update_t<FAST>(p[q], m1[q], m2[q], 0.0f, a.ac, sc_cur);
+                            p[q] = post(p[q]);
+                        }
+                    }
+                    sc_cur = sc_next;
+                    ++k;
+                }
+                if (k >= a.K) break;
+                // ---- event step k ----
+                scp += 4;
+                const StepScalars sc_next = load_scalars_at(scp);
                 if constexpr (!GRL) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) gr[q] = 0.0f;
                 }
                 bool hit = false;
                 int h0 = 0;
-                if (__builtin_expect(k == next_evt, 0)) {
+                {
                     // a wave with an event is on somebody's critical chain, the waves on the common path have slack:
                     // it issues ahead of them until its step is done
                     __builtin_amdgcn_s_setprio(3);
@@ -686,11 +744,9 @@ void resident_train_kernel(ResidentArgs a)
                     }
                     if (np == k + W) {                             // entries that enter the window now
                         [[maybe_unused]] const u64 rs_p0 = RS_NOW();
-                        StepScalars scw[W];
-                        load_window_scalars(k - 1, scw);
                         const int g0 = pc;
                         do {
-                            publish_entry(pc, k - 1, hc, g0, 0, 0, false, scw);
+                            publish_entry(pc, k - 1, hc, g0, 0, 0, false);
                             ++pc;
                             np = step_at(pc);
                         } while (np == k + W);
@@ -719,7 +775,9 @@ void resident_train_kernel(ResidentArgs a)
                         pf_key = kEventNone;
                         if (!alive) break;
                     }
+#ifndef MFCD_EXP_NOPF
                     if (nh == k + 1) prefetch_entry(hc);
+#endif
                     next_evt = next_event(k);
                     if (!hit) __builtin_amdgcn_s_setprio(0);
                     RS_ADD(1, RS_NOW() - rs_e0);
@@ -730,10 +788,13 @@ void resident_train_kernel(ResidentArgs a)
                     __builtin_amdgcn_s_setprio(0);
                 }
                 sc_cur = sc_next;
+                ++k;
             }
             __builtin_amdgcn_s_setprio(0);
 #ifdef MFCD_RES_STATS
             rs_acc[0] = RS_NOW() - rs_l0;
+            rs_acc[6] |= (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32;    // HW_ID: wave / SIMD / CU / SH / SE
+            rs_acc[5] |= (u64)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;   // XCC_ID
             if (lane == 0 && a.dbg)
                 for (int x = 0; x < 8; ++x) a.dbg[8 + (int64_t)gw * 8 + x] = rs_acc[x];
 #endif
@@ -785,9 +846,7 @@ void resident_train_kernel(ResidentArgs a)
 
     // ---- write my slice back (the table pointers are re-read: they were not kept live across the loop) ----
     // (after an expired wait the values are undefined but the status word says so; the store keeps the exit path single)
-    const ResidentCold *cp = a.cold;
-    asm volatile("" : "+s"(cp));   // opaque to the optimiser: forces fresh scalar loads instead of 12 live SGPRs
-    const ResidentCold c = *cp;
+    const ResidentCold c = *a.cold;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int64_t e = ebase + q * 64 + lane;

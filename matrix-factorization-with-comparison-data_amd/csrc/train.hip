@@ -522,12 +522,7 @@ TrainLayout train_layout(int64_t N_cap, int B, int n, int m, int d)
     if (L.resident) {
         b_off += align256(sizeof(mfcd_sample) * (size_t)Nc);
         L.mailbox_off = b_off;
-#ifdef MFCD_STAMPS
-        // diagnostic build: publish timestamps, one u64 per (sample, role), directly behind the mailbox
-        b_off += align256(L.mailbox_bytes + sizeof(unsigned long long) * (size_t)Nc * 3 + (size_t)4096 * 128 * 32);   // + hit trace
-#else
         b_off += align256(L.mailbox_bytes);
-#endif
     }
     L.alt_end = a_off;
     L.total = a_off > b_off ? a_off : b_off;
@@ -650,7 +645,7 @@ extern "C" int mfcd_set_tuning(int key, int64_t value)
             t.resident_wpc = (int)value;
             return 0;
         case MFCD_TUNE_RESIDENT_LOOKAHEAD:
-            if (value != -1 && value != 0 && value != 4 && value != 8) return MFCD_EINVAL;
+            if (value < -1 || value == 1 || value > 16) return MFCD_EINVAL;
             t.lookahead = (int)value;
             return 0;
         case MFCD_TUNE_RESIDENT_LDS_PAD:
@@ -676,13 +671,6 @@ extern "C" int mfcd_set_tuning(int key, int64_t value)
     }
 }
 
-#ifdef MFCD_STAMPS
-// diagnostic build only (tools/trace_resident.py): where the mailbox starts inside a workspace planned for these sizes
-extern "C" size_t mfcd_diag_mailbox_offset(int64_t N_cap, int B, int n, int m, int d)
-{
-    return train_layout(N_cap, B, n, m, d).mailbox_off;
-}
-#endif
 
 extern "C" size_t mfcd_train_workspace_bytes(int64_t N, int B, int n, int m, int d)
 {

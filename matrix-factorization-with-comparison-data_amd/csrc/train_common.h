@@ -153,7 +153,7 @@ constexpr unsigned kSpinLimitDefault = 1u << 22;  // polls before a wave gives u
 struct Tuning {
     int resident_q = 0;          // 0 = smallest slice that fits; else force Q
     int resident_wpc = 16;       // waves per CU bound for Q <= 2
-    int lookahead = -1;          // -1 auto (4, or 0 for tiny tables), 0 off, 4, 8
+    int lookahead = -1;          // -1 auto (4, or 0 for tiny tables), 0 off, else the window depth 2 .. 16
     int lds_pad = 0;             // unused dynamic LDS per workgroup (bytes)
     unsigned spin_limit = kSpinLimitDefault;   // polls before a wave gives up and sets the status word
     int stream_chunks = 0;       // streaming form: 16-byte chunks per thread and array (0 = by table size)
@@ -183,7 +183,7 @@ struct ResidentEvents {
 };
 ResidentEvents resident_events(int B, int n, int m, int d, int num_cus);
 constexpr int kResidentEventCap = 64;          // entries per (wave, chunk) list = one per lane (resident_kernel.h)
-constexpr int kResidentEventLook = 8;          // deepest look-ahead window: boundary copies per chunk
+constexpr int kResidentEventLook = 16;         // deepest look-ahead window: boundary copies per chunk
 inline int64_t resident_event_chunks(int64_t K, int tshift) { return (K >> tshift) + 2; }
 
 // One kernel in front of a resident / local launch: pinned staging slot -> workspace, and (xs != nullptr) the

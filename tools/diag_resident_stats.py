@@ -28,8 +28,12 @@ ms = e0.elapsed_time(e1)
 ws = engine.workspace_for(dev).buf
 raw = ws[256:256 + 64 + 4096 * 64].view(torch.int64).cpu().numpy()
 print("first give-up record (wave, step, pos, what):", raw[:4])
-dbg = raw[8:].reshape(-1, 8)
+dbg = raw[8:].reshape(-1, 8).copy()
 dbg = dbg[dbg[:, 0] > 0]
+hw_id = (dbg[:, 6] >> 32) & 0xFFFFFFFF
+xcc = (dbg[:, 5] >> 32) & 0xF
+dbg[:, 6] &= 0xFFFFFFFF
+dbg[:, 5] &= 0xFFFFFFFF
 tot = dbg[:, 0].mean()
 tick_us = dbg[:, 0].max() / (ms * 1e3)          # the slowest wave's loop ~ the launch
 print(f"waves {len(dbg)}  call {ms*1e3:.0f} us = {ms*1e3/K:.3f} us/step; step loop of a wave: mean {tot:.0f} max {dbg[:,0].max()} ticks "
@@ -59,3 +63,25 @@ for lo, hi in ((0, 35), (35, 45), (45, 55), (55, 65), (65, 400)):
     if sel.any():
         print(f"  waves with {lo:3d}-{hi:3d} hits: n={sel.sum():4d}  event-step time {dbg[sel,1].mean()/tick_us:6.0f} us  wait {dbg[sel,2].mean()/tick_us:6.0f} us  "
               f"publish {dbg[sel,3].mean()/tick_us:5.0f} us  busy {busy[sel].mean():6.0f} us")
+
+# placement: which SIMD of which CU a wave ran on (HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID)
+simd = (hw_id >> 4) & 3
+cu = (hw_id >> 8) & 15
+sh = (hw_id >> 12) & 1
+se = (hw_id >> 13) & 7
+cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+simd_key = cu_key * 4 + simd
+common = (dbg[:, 0] - dbg[:, 1]) / tick_us / K            # us per step outside event steps
+uc, cnt_cu = np.unique(cu_key, return_counts=True)
+us_, cnt_simd = np.unique(simd_key, return_counts=True)
+print(f"placement: {len(uc)} CUs hold waves; waves per CU min/median/max {cnt_cu.min()}/{int(np.median(cnt_cu))}/{cnt_cu.max()} "
+      f"(histogram {dict(zip(*np.unique(cnt_cu, return_counts=True)))}); waves per SIMD histogram {dict(zip(*np.unique(cnt_simd, return_counts=True)))}")
+per_simd = dict(zip(us_, cnt_simd))
+crowd = np.array([per_simd[k_] for k_ in simd_key])
+for cval in np.unique(crowd):
+    sel = crowd == cval
+    print(f"  waves on a SIMD with {cval} waves: n={sel.sum():4d}  common path {common[sel].mean():.3f} us/step  busy {busy[sel].mean():5.0f} us  wait {wait_us[sel].mean():5.0f} us")
+pc = np.percentile(common, [0, 5, 50, 95, 100])
+print("per-wave common-path us/step percentiles 0/5/50/95/100: " + " ".join(f"{v:.3f}" for v in pc))
+byx = [busy[xcc == x].mean() for x in range(8) if (xcc == x).any()]
+print("mean busy by XCC: " + " ".join(f"{v:.0f}" for v in byx) + "   waves by XCC: " + " ".join(str(int((xcc == x).sum())) for x in range(8)))
