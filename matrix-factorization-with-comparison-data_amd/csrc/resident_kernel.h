@@ -15,8 +15,7 @@ typedef unsigned long long u64;
 // Diagnostic build (-DMFCD_RES_STATS, tools/diag_resident_stats.py only): per-wave cycle / event accounting of the
 // look-ahead loop, written to dbg[8 + wave*8 ..]:
 //   0 whole step loop  1 event steps (everything between "k == next_evt" and the dense update)  2 granule polls that
-//   had to wait (from the first failed poll to success)  3 publish passes  4 hits | hits served from the one-step-ahead
-//   request << 20 | hits whose first poll succeeded << 40   5 failed polls | XCC_ID << 32  6 kernel start -> first step | HW_ID << 32
+//   had to wait (from the first failed poll to success)  3 publish passes  4 hits | hits whose first poll succeeded << 40   5 failed polls | XCC_ID << 32  6 kernel start -> first step | HW_ID << 32
 //   7 rows published | event steps << 32
 #ifdef MFCD_RES_STATS
 #define RS_NOW() ((u64)__builtin_amdgcn_s_memtime())
@@ -99,8 +98,8 @@ __host__ __device__ inline RowMap make_row_map(int n, int m)
 // [cT, (c+1)T), plus a copy of the entries of the first LOOK steps of chunk c + 1 (the look-ahead window reaches across
 // the boundary), at most kEventCap of them, in arrival order of the prologue's atomics.  The wave loads a chunk's list
 // into ONE entry per lane, sorts it by (step, slot in the batch) and from then on decides everything — is there a hit at
-// this step, which row is due for publishing and into which mailbox slot, which granules to request a step ahead — with
-// ballots and v_readlane on three registers: no record load sits in front of a hit or a publish any more (round 2: two
+// this step, which row is due for publishing and into which mailbox slot — with v_readlane on its registers and two
+// scalar cursors: no record load sits in front of a hit or a publish any more (round 2: two
 // dependent memory round trips per hit), and the per-step path of a wave without events is one scalar compare.
 //   word 0: step k << 9 | slot in the batch << 3 | own-role mask (bit r: the sample's role r = u, i, j is a row of mine)
 //   word 1: my local row index of role 0 | role 1 << 10 | role 2 << 20   (valid where the own bit is set)
@@ -278,20 +277,14 @@ void resident_train_kernel(ResidentArgs a)
         }
     };
 
-    // granules requested ONE STEP AHEAD for the first hit of the next step (look-ahead form): pf_key names the entry
-    [[maybe_unused]] u64 pf[3][S];
-    [[maybe_unused]] unsigned pf_key = kEventNone;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s2 = 0; s2 < S; ++s2) pf[r][s2] = 0ull;
-
     // One sample that names rows of mine (own0..2: which roles; lr0..2: my local rows of those roles): fetch the other
     // rows, form g, accumulate the row gradients of my rows.  `pos` is the sample's position in the call, `tag` its
-    // step's tag.  pre: the foreign granules were requested a step ahead and sit in pf.  Returns false when a bounded
-    // wait expired.
+    // step's tag.  Returns false when a bounded wait expired.
+    // (Requesting the granules one step ahead — an extra event step per hit that only issues the loads — was built
+    // and measured in round 3: same step time with and without it at every window depth; the launch is bound by the
+    // SIMDs' issue slots, not by this round trip, so the simpler form stays.)
     auto process_hit = [&](bool own0, bool own1, bool own2, int lr0, int lr1, int lr2, float zz, int64_t pos,
-                           unsigned tag, float inv_batch, bool pre, int step) MFCD_LAMBDA_INLINE -> bool {
+                           unsigned tag, float inv_batch, int step) MFCD_LAMBDA_INLINE -> bool {
         const bool own[3] = {own0, own1, own2};
         const int lrs[3] = {lr0, lr1, lr2};
         const u64 *slot = a.mailbox + pos * 3 * D;
@@ -319,9 +312,8 @@ void resident_train_kernel(ResidentArgs a)
         }
         // rows owned by other waves: their granules, polled until every tag is this step's
         unsigned spins = 0, limit = 0;
-        bool have = pre;
         [[maybe_unused]] u64 rs_w0 = 0;
-        RS_ADD(4, 1ull | (pre ? 1ull << 20 : 0ull));
+        RS_ADD(4, 1ull);
         while (true) {
             bool ok = true;
 #pragma unroll
@@ -331,14 +323,13 @@ void resident_train_kernel(ResidentArgs a)
                 for (int s2 = 0; s2 < S; ++s2) {
                     const int c = lane + 64 * s2;
                     if (c < D) {
-                        const u64 gq = have ? pf[r][s2] : load_granule(slot + (int64_t)r * D + c);
+                        const u64 gq = load_granule(slot + (int64_t)r * D + c);
                         ok = ok && ((unsigned)(gq >> 32) == tag);
                         row[r][s2] = __uint_as_float((unsigned)gq);
                     }
                 }
             }
             if (__all(ok)) break;
-            have = false;
 #ifdef MFCD_RES_STATS
             if (spins == 0) rs_w0 = RS_NOW();
             RS_ADD(5, 1);
@@ -347,26 +338,6 @@ void resident_train_kernel(ResidentArgs a)
                 give_up(step, pos, (own0 ? 1 : 0) | (own1 ? 2 : 0) | (own2 ? 4 : 0));
                 return false;
             }
-#ifdef MFCD_EXP_SLEEP
-            __builtin_amdgcn_s_sleep(MFCD_EXP_SLEEP);   // timing experiment (tools/): back off between failed polls
-#endif
-#ifdef MFCD_EXP_POLL1
-            // timing experiment (tools/): after a failed poll watch ONE granule per foreign row (8 bytes instead of 8 D)
-            // until its tag is this step's, then read the rows
-            while (true) {
-                bool ok1 = true;
-                if (lane == 0) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        if (!own[r]) ok1 = ok1 && ((unsigned)(load_granule(slot + (int64_t)r * D) >> 32) == tag);
-                }
-                if (__builtin_amdgcn_readfirstlane((int)ok1)) break;
-                if (poll_failed(spins, limit)) {
-                    give_up(step, pos, 16);
-                    return false;
-                }
-            }
-#endif
         }
 #ifdef MFCD_RES_STATS
         if (spins) RS_ADD(2, RS_NOW() - rs_w0);
@@ -495,7 +466,7 @@ void resident_train_kernel(ResidentArgs a)
                     const float hz = __shfl(s.z, tl, MFCD_WAVE);
                     const bool ok = process_hit((bool)((M.mu >> tl) & 1ull), (bool)((M.mi >> tl) & 1ull),
                                                 (bool)((M.mj >> tl) & 1ull), hu, hi, hj, hz, pos0 + base + tl,
-                                                a.tag_base + (unsigned)k + 1u, inv_batch, false, k);
+                                                a.tag_base + (unsigned)k + 1u, inv_batch, k);
                     if (__builtin_amdgcn_readfirstlane((int)!ok)) return false;
                 }
             }
@@ -643,44 +614,18 @@ void resident_train_kernel(ResidentArgs a)
                 }
                 RS_ADD(3, RS_NOW() - rs_p0);
             };
-            // request, one step ahead, the foreign granules of entry idx
-            auto prefetch_entry = [&](int idx) MFCD_LAMBDA_INLINE {
-                const unsigned key1 = (unsigned)__builtin_amdgcn_readlane((int)ekey, idx);
-                const int k1 = (int)(key1 >> 9);
-                const int tl = (int)((key1 >> 3) & 63u);
-                const u64 *slot = a.mailbox + ((int64_t)k1 * a.B + tl) * 3 * D;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    if ((key1 >> r) & 1u) continue;
-#pragma unroll
-                    for (int s2 = 0; s2 < S; ++s2) {
-                        const int c = lane + 64 * s2;
-                        if (c < D) pf[r][s2] = load_granule(slot + (int64_t)r * D + c);
-                    }
-                }
-                pf_key = key1;
-            };
-
             load_chunk(0);
             int hc = 0, pc = __builtin_popcountll(__ballot(estep < W));
             publish_fresh(-1, 0, pc, 0, 0);                        // first uses within the first W steps, from the initial state
             int nh = step_at(0), np = step_at(pc);
-#ifndef MFCD_EXP_NOPF
-            if (nh == 0) prefetch_entry(0);
-#endif
-            // the next step at which this wave has anything to do besides its dense update: a hit (be there one step
-            // early for the granule request), an entry entering the window, the end of the chunk
-            auto next_event = [&](int k) MFCD_LAMBDA_INLINE -> int {
-#ifdef MFCD_EXP_NOPF
-                const int ch = nh;                                 // timing experiment (tools/): no request one step ahead
-#else
-                const int ch = nh - 1 > k ? nh - 1 : k + 1;
-#endif
+            // the next step at which this wave has anything to do besides its dense update: a hit, an entry entering
+            // the window, the end of the chunk
+            auto next_event = [&]() MFCD_LAMBDA_INLINE -> int {
                 const int cp = np - W;
-                const int e = ch < cp ? ch : cp;
+                const int e = nh < cp ? nh : cp;
                 return e < chunk_end ? e : chunk_end;
             };
-            int next_evt = next_event(-1);
+            int next_evt = next_event();
 
             // The step loop is cut at this wave's events: between two of them the wave runs QUIET steps — scalars of the
             // next step requested, dense update with a literal zero gradient, counter — in a loop of its own with no
@@ -762,23 +707,18 @@ void resident_train_kernel(ResidentArgs a)
                             const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)ekey, hc);
                             const unsigned row_l = (unsigned)__builtin_amdgcn_readlane((int)erow, hc);
                             const float z_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ez), hc));
-                            const bool pre = key_l == pf_key;
                             // the abort decision is wave-uniform; saying so keeps the step loop free of exec-mask bookkeeping
                             const bool ok = process_hit((bool)(key_l & 1u), (bool)(key_l & 2u), (bool)(key_l & 4u),
                                                         (int)(row_l & 1023u), (int)((row_l >> 10) & 1023u),
                                                         (int)((row_l >> 20) & 1023u), z_l,
-                                                        (int64_t)k * a.B + (int)((key_l >> 3) & 63u), tag, inv_batch, pre, k);
+                                                        (int64_t)k * a.B + (int)((key_l >> 3) & 63u), tag, inv_batch, k);
                             if (__builtin_amdgcn_readfirstlane((int)!ok)) { alive = false; break; }
                             ++hc;
                             nh = step_at(hc);
                         } while (nh == k);
-                        pf_key = kEventNone;
                         if (!alive) break;
                     }
-#ifndef MFCD_EXP_NOPF
-                    if (nh == k + 1) prefetch_entry(hc);
-#endif
-                    next_evt = next_event(k);
+                    next_evt = next_event();
                     if (!hit) __builtin_amdgcn_s_setprio(0);
                     RS_ADD(1, RS_NOW() - rs_e0);
                 }

@@ -39,14 +39,13 @@ tick_us = dbg[:, 0].max() / (ms * 1e3)          # the slowest wave's loop ~ the 
 print(f"waves {len(dbg)}  call {ms*1e3:.0f} us = {ms*1e3/K:.3f} us/step; step loop of a wave: mean {tot:.0f} max {dbg[:,0].max()} ticks "
       f"(~{tick_us:.0f} ticks/us if the slowest loop is the launch)")
 hits = dbg[:, 4] & 0xFFFFF
-pre = (dbg[:, 4] >> 20) & 0xFFFFF
 first_ok = (dbg[:, 4] >> 40) & 0xFFFFF
 pubs = dbg[:, 7] & 0xFFFFFFFF
 evs = dbg[:, 7] >> 32
 H = hits.sum()
-print(f"hits {H} ({H/K:.1f}/step, {H/len(dbg):.1f}/wave); with granules requested a step ahead {pre.sum()} ({pre.sum()/H*100:.0f}%); "
+print(f"hits {H} ({H/K:.1f}/step, {H/len(dbg):.1f}/wave); "
       f"first poll succeeded {first_ok.sum()} ({first_ok.sum()/H*100:.0f}%); failed polls {dbg[:,5].sum()} ({dbg[:,5].sum()/H:.2f}/hit)")
-print(f"event steps {evs.sum()} ({evs.sum()/len(dbg):.1f}/wave = {evs.sum()/len(dbg)/K*100:.1f}% of steps); publish passes that stored {pubs.sum()}")
+print(f"event steps {evs.sum()} ({evs.sum()/len(dbg):.1f}/wave = {evs.sum()/len(dbg)/K*100:.1f}% of steps); rows published {pubs.sum()}")
 print(f"share of a wave's loop time: event steps {dbg[:,1].mean()/tot*100:.1f}% (of which waiting polls {dbg[:,2].mean()/tot*100:.1f}%, "
       f"publish passes {dbg[:,3].mean()/tot*100:.1f}%); per event step {dbg[:,1].sum()/evs.sum()/tick_us:.2f} us; "
       f"per waited poll {dbg[:,2].sum()/max((hits-first_ok).sum(),1)/tick_us:.2f} us; per publish pass {dbg[:,3].sum()/max(pubs.sum(),1)/tick_us:.2f} us")

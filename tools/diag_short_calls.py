@@ -65,7 +65,7 @@ engine.check_status()
 # host-side split of one call: Python before / the C-ABI call itself / Python after
 from mfcd import _lib
 L = _lib.load()
-real = L.mfcd_train_steps
+real = L.mfcd_train_call_run
 spans = []
 
 
@@ -76,7 +76,7 @@ def timed_entry(*a):
     return rc
 
 
-L.mfcd_train_steps = timed_entry
+L.mfcd_train_call_run = timed_entry
 tot, pre, cabi, post = [], [], [], []
 for c in range(60):
     torch.cuda.synchronize()
@@ -85,6 +85,6 @@ for c in range(60):
     t1 = time.perf_counter()
     a, b = spans[-1]
     tot.append(t1 - t0); pre.append(a - t0); cabi.append(b - a); post.append(t1 - b)
-L.mfcd_train_steps = real
+L.mfcd_train_call_run = real
 med = lambda x: sorted(x)[len(x) // 2] * 1e6
 print(f"host split (median of 60): total {med(tot):.1f} us = python before {med(pre):.1f} + C-ABI call {med(cabi):.1f} + python after {med(post):.1f}")
