@@ -128,7 +128,7 @@ int mfcd_set_resident_math(int fast);
  */
 #define MFCD_TUNE_RESIDENT_Q 1          /* 0 = smallest slice that fits (default); 1, 2, 4, 16 force it          */
 #define MFCD_TUNE_RESIDENT_WPC 2        /* waves per CU for slices of <= 2 registers: 16 (default) or 8        */
-#define MFCD_TUNE_RESIDENT_LOOKAHEAD 3  /* -1 auto (default), 0 off, 4, 8                                      */
+#define MFCD_TUNE_RESIDENT_LOOKAHEAD 3  /* -1 auto (default: 4), 0 off, 2 .. 16 = depth of the window in steps */
 #define MFCD_TUNE_RESIDENT_LDS_PAD 4    /* unused dynamic LDS per workgroup, bytes (default 0)                 */
 #define MFCD_TUNE_RESIDENT_SPIN_LIMIT 5 /* polls before a wave gives up; 0 = default (2^22)                    */
 #define MFCD_TUNE_SHORT_CALL_STEPS 6    /* "auto": calls of fewer steps stream instead (default 3)             */

@@ -200,6 +200,8 @@ struct InlineStage {
     uint4 v[kInlineStageUnits];
 };
 
+size_t train_inline_stage_bytes() { return (size_t)kInlineStageUnits * 16; }
+
 __device__ __forceinline__ void event_append(unsigned *__restrict__ ev_cnt, uint4 *__restrict__ ev_ent, size_t list,
                                              const uint4 &e)
 {

@@ -787,8 +787,13 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
         void *terms = base + L.terms_off;
         StageSlot *slot = nullptr;
         const size_t need = kColdBytes + sizeof(StepScalars) * (size_t)(nsteps + 1);
-        if (int rc = stage_acquire(*S, need, &slot)) return rc;
-        void **cold = (void **)slot->host;   // ResidentCold (resident_kernel.h)
+        // short calls: the table is built on this thread's stack and copied into the prologue's kernel arguments at launch
+        alignas(16) unsigned char inline_stage[4096];
+        const bool stage_inline = need <= mfcd_detail::train_inline_stage_bytes() && need <= sizeof(inline_stage);
+        if (!stage_inline)
+            if (int rc = stage_acquire(*S, need, &slot)) return rc;
+        void *const stage_host = stage_inline ? (void *)inline_stage : slot->host;
+        void **cold = (void **)stage_host;   // ResidentCold (resident_kernel.h)
         cold[0] = U; cold[1] = V; cold[2] = mU; cold[3] = vU; cold[4] = mV; cold[5] = vV; cold[6] = status;
         cold[7] = (void *)(uintptr_t)mfcd_detail::g_tune.spin_limit;
         cold[8] = base + L.evcnt_off;
@@ -797,7 +802,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
         cold[11] = (void *)(uintptr_t)fc.rp.tshift;
         cold[12] = means_inside ? (void *)loss_per_step : nullptr;
         for (int k = 13; k < 16; ++k) cold[k] = nullptr;
-        StepScalars *sc_host = (StepScalars *)((char *)slot->host + kColdBytes);
+        StepScalars *sc_host = (StepScalars *)((char *)stage_host + kColdBytes);
         for (int64_t k = 0; k <= nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
 
         mfcd_sample *xs = resident ? (mfcd_sample *)(base + L.xs_off) : nullptr;
@@ -826,7 +831,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
         if (!means_inside) S->terms_dirty = true;
         const int rpw = resident ? 64 * fc.rp.Q / d : 0;
         const int look = means_inside ? fc.rp.lookahead : 0;
-        if (int rc = mfcd_detail::launch_train_prologue(slot->host, slot->devview, base + L.stage_off, need, samples, N, B, n,
+        if (int rc = mfcd_detail::launch_train_prologue(stage_host, stage_inline ? nullptr : slot->devview, base + L.stage_off, need, samples, N, B, n,
                                                         m, rpw, fc.rp.tshift, look, L.nch_cap, xs,
                                                         (unsigned *)(base + L.evcnt_off), base + L.event_off, st))
             return rc;
@@ -855,8 +860,10 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
         }
         // the slot is free again once the prologue has read it; recorded behind the call's last launch so that the
         // record does not sit between two launches (any later point of the stream implies the prologue is done)
-        MFCD_HIP_TRY(hipEventRecord(slot->ev, st));
-        slot->pending = true;
+        if (slot) {
+            MFCD_HIP_TRY(hipEventRecord(slot->ev, st));
+            slot->pending = true;
+        }
         if (timing_us) {
             MFCD_HIP_TRY(hipEventSynchronize(e1));
             float ms = 0.0f;

@@ -186,6 +186,10 @@ constexpr int kResidentEventCap = 64;          // entries per (wave, chunk) list
 constexpr int kResidentEventLook = 16;         // deepest look-ahead window: boundary copies per chunk
 inline int64_t resident_event_chunks(int64_t K, int tshift) { return (K >> tshift) + 2; }
 
+// stage tables of up to this many bytes travel in the prologue kernel's own argument segment: the host buffer they are
+// built in is read at launch time only (no pinned slot, no event)
+size_t train_inline_stage_bytes();
+
 // One kernel in front of a resident / local launch: pinned staging slot -> workspace, and (xs != nullptr) the
 // translated samples + (look > 0) the per-wave event lists of the resident form.
 int launch_train_prologue(const void *stage_host, const void *stage_host_devview, void *stage_dev, size_t stage_bytes,

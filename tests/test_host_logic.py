@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     # pure host helpers may be called without a GPU
     assert L.mfcd_train_workspace_bytes(1000, 64, 16, 16, 8) >= 2 * 16 * 8 * 4 + 4000
     # an unregistered workspace is refused before anything touches the device; tuning setters validate their input
-    assert L.mfcd_set_tuning(_lib.TUNE_KEYS["resident_lookahead"], 5) == -1
+    assert L.mfcd_set_tuning(_lib.TUNE_KEYS["resident_lookahead"], 17) == -1
     assert L.mfcd_set_tuning(_lib.TUNE_KEYS["resident_lookahead"], -1) == 0
     assert L.mfcd_train_workspace_release(None) == 0
     assert L.mfcd_error_string(-6).decode().startswith("mfcd: workspace not initialised")
