@@ -119,11 +119,15 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restr
 // works on fp32 tensors).  A workgroup first forms ubar, vbar = (sum over slices) / rows from the partial column sums
 // (fixed order; every workgroup repeats this small reduction instead of a launch of its own), then takes
 // `rows_per_block` consecutive rows of [U; V], one wave per row.
+// vsplit != nullptr (split-product form of the main kernel, d a multiple of 16): every V row is also written as its
+// two-term bf16 expansion v = hi + mid (+ 2^-16 |v|), hi = bf16(v), mid = bf16(v - hi), in the FRAGMENT-MAJOR layout the
+// main kernel's MFMA operand reads want: [32-row tile][16-wide k block][part hi / mid][lane = (k / 8 % 2) * 32 + row % 32]
+// [8 bf16] — one wave-level 16-byte read per (tile, k block, part) is one contiguous KiB.
 __global__ __launch_bounds__(256) void centre_vectors_kernel(const float *__restrict__ U, const float *__restrict__ V,
                                                              const double *__restrict__ part,
                                                              const float *__restrict__ bar_pre, int n, int m, int d,
                                                              int rows_per_block, float *__restrict__ rm,
-                                                             float *__restrict__ cm)
+                                                             float *__restrict__ cm, mfcd_bf16 *__restrict__ vsplit)
 {
     extern __shared__ __attribute__((aligned(16))) float bar[];   // [2][d]: ubar, vbar
     for (int idx = threadIdx.x; idx < 2 * d; idx += 256) {
@@ -154,6 +158,19 @@ __global__ __launch_bounds__(256) void centre_vectors_kernel(const float *__rest
         const float *other = isV ? bar : bar + d;  // V rows pair with ubar (bar[0]), U rows with vbar (bar[1])
         double acc = 0.0;
         for (int k = lane; k < d; k += MFCD_WAVE) acc += (double)row[k] * (double)other[k];
+        if (isV && vsplit) {
+            const int64_t c = w - n;
+            const int64_t tile_base = (c >> 5) * (int64_t)(d >> 4);        // (tile, k block) index of k block 0
+            const int l31 = (int)(c & 31);
+            for (int k = lane; k < d; k += MFCD_WAVE) {
+                const float x = row[k];
+                const mfcd_bf16 hi = (mfcd_bf16)x;
+                const mfcd_bf16 mid = (mfcd_bf16)(x - (float)hi);
+                const int64_t chunk = ((tile_base + (k >> 4)) * 2) * 64 + ((k >> 3) & 1) * 32 + l31;   // part 0
+                vsplit[chunk * 8 + (k & 7)] = hi;
+                vsplit[(chunk + 64) * 8 + (k & 7)] = mid;
+            }
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, MFCD_WAVE);
         if (lane == 0) {
@@ -404,20 +421,39 @@ __device__ __forceinline__ void lds_wait4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 
+__device__ __forceinline__ void split_read_batch(f32x4 (&t)[4], unsigned abase, int bi)
+{
+    switch (bi) {   // folded: bi is a constant in the unrolled caller
+#define MFCD_B(B) case B: lds_read16_issue<(4 * B + 0) * 1024>(t[0], abase); lds_read16_issue<(4 * B + 1) * 1024>(t[1], abase); \
+                  lds_read16_issue<(4 * B + 2) * 1024>(t[2], abase); lds_read16_issue<(4 * B + 3) * 1024>(t[3], abase); break;
+        MFCD_B(0) MFCD_B(1) MFCD_B(2) MFCD_B(3)
+#undef MFCD_B
+    default: break;
+    }
+}
+
 // PFX: fetch a tile's X values one tile ahead (needs ~45 more registers: two register sets, two copies of the tile
 // body).  On for d <= 128, where an HBM round trip outlasts a tile's MFMA chain; off for d = 256, whose 128-MFMA chain
 // covers it and whose 128-register operand leaves no room.
 // WHAT: 1 = per-row sums only (compute_alpha_and_norm_ratios never reads the global error), 2 = global error sum only
 // (compute_reconstruction_error never reads the rows), 3 = both.  The epilogue's vector work runs on the lanes the fp32
 // MFMA uses, so what the caller does not need is not computed: 7 / 3 / 10 packed operations per pair of outputs.
-template <int D, int NW, int TC, bool XV, int WPE = 2, bool PFX = (D <= 128), int WHAT = 3>
+// SPLIT: the product runs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the rate of the fp32 MFMA) as THREE
+// bf16 products with fp32 accumulation: u = uh + um, v = vh + vm (two-term bf16 expansions, 16 significant bits each),
+// u v ~ vm uh + vh um + vh uh; the dropped terms are <= 2^-16 |u v| each, the measured error of a row sum of U V^T is
+// 3-4e-6 relative (tests hold 2e-5; the reference's own fp32 GEMM is at 1e-7).  `V` then points at the split table in
+// the fragment-major layout centre_vectors_kernel writes (same bytes per row, same stage and piece arithmetic; a
+// wave's fragment read is one contiguous KiB, so the stage needs no padding), and the wave splits its own U rows once.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int D, int NW, int TC, bool XV, int WPE = 2, bool PFX = (D <= 128), int WHAT = 3, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE)))
 void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ X,
                       const float *__restrict__ rm, const float *__restrict__ cm, int n,
                       int m, float s, int cols_per_split, int splits, int row_blocks, double *__restrict__ part_rows,
                       double *__restrict__ part_err, double *__restrict__ part_xx)
 {
-    constexpr int CPR = D / 4, PIECES = TC * D / 256, PPW = PIECES / NW, CMW = (TC + 63) / 64, PF = 260;
+    constexpr int CPR = D / 4, PIECES = TC * D / 256, PPW = PIECES / NW, CMW = (TC + 63) / 64, PF = SPLIT ? 256 : 260;
+    static_assert(!SPLIT || (D % 32 == 0 && D <= 128 && PFX && XV), "split-product form: d in {32, 64, 128}, prefetch form");
     static_assert(PIECES % NW == 0 && TC % 32 == 0 && CMW <= NW, "stage must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) float vts[2][PIECES * PF];   // [buffer][piece][256 + 4 pad]
     __shared__ __attribute__((aligned(16))) float cmss[2][CMW * 64];      // column means of U V^T, stage's columns
@@ -446,7 +482,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     const int dma0 = (wave * PPW * 64 + lane) * 4;
     auto issue_stage = [&](int c0, float *vt, float *cms) {
         const int base = c0 * D + dma0;
-        if (c0 + TC <= m) {
+        if (SPLIT || c0 + TC <= m) {      // (the split table is padded to whole stages)
             const float *vb = V + base;   // one 64-bit address per stage, the pieces are 1 KiB apart
 #pragma unroll
             for (int i = 0; i < PPW; ++i) lds_dma16(vb + i * 256, vt + (wave * PPW + i) * PF);
@@ -461,8 +497,23 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     };
     issue_stage(c_begin, vts[0], cmss[0]);
 
-    float u[D / 2];   // B operand: this lane's half of its U row (k index permuted: lane half h, step kk -> h*D/2+kk)
-    {
+    float u[SPLIT ? 1 : D / 2];   // B operand: this lane's half of its U row (k index permuted: lane half h, step kk -> h*D/2+kk)
+    bf16x8 uh[SPLIT ? D / 16 : 1], um[SPLIT ? D / 16 : 1];   // split form: k block kb, elements k = 16 kb + 8 half + 0..7
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int kb = 0; kb < D / 16; ++kb) {
+            const float *up = U + (int64_t)myrow * D + kb * 16 + half * 8;
+            const float4 t0 = *reinterpret_cast<const float4 *>(up), t1 = *reinterpret_cast<const float4 *>(up + 4);
+            const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const mfcd_bf16 hi = (mfcd_bf16)x[e];
+                uh[kb][e] = hi;
+                um[kb][e] = (mfcd_bf16)(x[e] - (float)hi);
+            }
+        }
+        u[0] = 0.0f;
+    } else {
         const float *urow = U + (int64_t)myrow * D + half * (D / 2);
 #pragma unroll
         for (int q = 0; q < D / 8; ++q) {
@@ -476,8 +527,13 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     float rmv = rm[myrow], x0v = X[(int64_t)myrow * m + c_begin];
     // every load so far is consumed HERE, before the loop: left pending, the wait for it would sit in front of the
     // first MFMA of every iteration (and, with an LDS-DMA in flight, be a full vmcnt(0))
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int k = 0; k < D / 2; ++k) asm volatile("" : "+v"(u[k]));
+        for (int kb = 0; kb < D / 16; ++kb) asm volatile("" : "+v"(uh[kb]), "+v"(um[kb]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < D / 2; ++k) asm volatile("" : "+v"(u[k]));
+    }
     asm volatile("" : "+v"(rmv), "+v"(x0v));
     const float *xrow0 = X + (int64_t)myrow * m;   // + cb + 8g + 4*half: this lane's 16-byte pieces of a tile
     // fragment address of tile j of a stage: row 32j + l31, chunks half*CPR/2 + q (one piece, consecutive)
@@ -539,10 +595,41 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                 // stage issued just above, and the DMA would never overlap the MFMA chain.  LDS returns in order, so
                 // "at most QB operations outstanding" means the older batch has landed (extra operations the compiler
                 // may have in flight only make the wait stricter).
-                constexpr int QB = 4, NB = D / 8 / QB;
-                const unsigned abase = lds_addr(vts[buf]) + frag0 + (unsigned)j * frag_step;
                 const unsigned cmaddr = lds_addr(cms + 32 * j + 4 * half);
                 f32x4 cq[4];
+                if constexpr (SPLIT) {
+                    // fragments of tile j: KiB number ((j * D/16 + kb) * 2 + part); this lane's 16 bytes at lane * 16
+                    constexpr int NKB = D / 16, NBS = NKB / 2;
+                    const unsigned abase = lds_addr(vts[buf]) + (unsigned)j * (unsigned)(NKB * 2 * 1024) + (unsigned)lane * 16u;
+                    f32x4 t[2][4];
+                    split_read_batch(t[0], abase, 0);
+#pragma unroll
+                    for (int bi = 0; bi < NBS; ++bi) {
+                        if (bi + 1 < NBS) {
+                            split_read_batch(t[(bi + 1) & 1], abase, bi + 1);
+                            lds_wait4<4>(t[bi & 1][0], t[bi & 1][1], t[bi & 1][2], t[bi & 1][3]);
+                        } else {
+                            lds_wait4<0>(t[bi & 1][0], t[bi & 1][1], t[bi & 1][2], t[bi & 1][3]);
+                            if constexpr ((WHAT & 2) != 0) {
+                                lds_read16_issue<0>(cq[0], cmaddr);
+                                lds_read16_issue<32>(cq[1], cmaddr);
+                                lds_read16_issue<64>(cq[2], cmaddr);
+                                lds_read16_issue<96>(cq[3], cmaddr);
+                            }
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const int kb = 2 * bi + kk;
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, t[bi & 1][2 * kk]);
+                            const bf16x8 am = __builtin_bit_cast(bf16x8, t[bi & 1][2 * kk + 1]);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, uh[kb], acc, 0, 0, 0);   // small terms first
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, um[kb], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, uh[kb], acc, 0, 0, 0);
+                        }
+                    }
+                } else {
+                constexpr int QB = 4, NB = D / 8 / QB;
+                const unsigned abase = lds_addr(vts[buf]) + frag0 + (unsigned)j * frag_step;
                 f32x4 t[2][QB];
                 lds_read16_issue<0>(t[0][0], abase);
                 lds_read16_issue<16>(t[0][1], abase);
@@ -578,6 +665,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq.z, u[k0 + 2], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tq.w, u[k0 + 3], acc, 0, 0, 0);
                     }
+                }
                 }
                 MFCD_STAMP(tt1);
                 // the X values become visible to the epilogue arithmetic only here: otherwise the scheduler moves
@@ -914,6 +1002,7 @@ __global__ __launch_bounds__(256) void uvt_rows_kernel(const float *__restrict__
 }
 
 struct UvtWs {
+    mfcd_bf16 *vsplit;   // split-product form: V as two bf16 terms, fragment-major, padded to whole stages (else nullptr)
     double *colpart;  // [2][kSlices][d]
     float *bar;       // [2][d]
     float *rm, *cm, *xm;
@@ -939,6 +1028,9 @@ TiledCfg tiled_cfg(int d)
     default: return {0, 0};
     }
 }
+
+int g_uvt_split = 1;           // mfcd_set_tuning(MFCD_TUNE_UVT_SPLIT): 1 = bf16x3 split-product main kernel where it applies
+bool split_form_applies(int d) { return g_uvt_split != 0 && (d == 32 || d == 64 || d == 128); }
 
 int g_uvt_target_wgs = 512;    // mfcd_set_tuning(MFCD_TUNE_UVT_TARGET_WGS): workgroups the tiled form aims for: one round of the chip (two
                                // per CU), then whatever the L2 rule below adds (C3: 617 us at 1024 workgroups, 639 us at 4096)
@@ -997,6 +1089,14 @@ UvtWs plan_ws(char *base, int n, int m, int d)
     w.blk = (double *)take(sizeof(double) * 2 * (size_t)w.nblk);
     w.dummy_rows = (double *)take(sizeof(double) * 8 * (size_t)n);   // output the caller did not ask for (select entry)
     w.dummy_scal = (double *)take(sizeof(double) * 4);
+    // split-product form (d in {32, 64, 128}): 4 d bytes per V row like the fp32 table, rows padded to whole stages plus one
+    // (the stage DMA never leaves the buffer)
+    w.vsplit = nullptr;
+    if (w.tiled && split_form_applies(d)) {
+        const size_t rows = ((size_t)m + tc.TC - 1) / tc.TC * tc.TC + tc.TC;
+        w.vsplit = (mfcd_bf16 *)take(rows * (size_t)d * 4);
+        if (!base) w.vsplit = (mfcd_bf16 *)(uintptr_t)1;   // size query: "would be allocated"
+    }
     w.bytes = off;
     return w;
 }
@@ -1009,6 +1109,14 @@ void launch_tiled_what(const UvtWs &w, const float *U, const float *V, const flo
 {
     const int row_blocks = (n + NW * 32 - 1) / (NW * 32);
     const unsigned blocks = (unsigned)row_blocks * (w.splits >= 8 ? 8u * ((w.splits + 7) / 8) : (unsigned)w.splits);
+    if constexpr (DD <= 128 && PFX) {
+        if (xv && w.vsplit) {   // bf16x3 split product: V comes from the split table centre_vectors_kernel wrote
+            hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, 2, true, WHAT, true>), dim3(blocks), dim3(NW * 64), 0, st, U,
+                               (const float *)w.vsplit, X, w.rm, w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks,
+                               w.part_rows, w.part_err, w.part_xx);
+            return;
+        }
+    }
     if (xv)
         hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, WPE, PFX, WHAT>), dim3(blocks), dim3(NW * 64), 0, st, U, V,
                            X, w.rm, w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err,
@@ -1043,6 +1151,13 @@ int set_uvt_min_stages(int v)
 {
     if (v < 1 || v > 64) return MFCD_EINVAL;
     g_uvt_min_stages = v;
+    return 0;
+}
+
+int set_uvt_split(int v)
+{
+    if (v != 0 && v != 1) return MFCD_EINVAL;
+    g_uvt_split = v;
     return 0;
 }
 
@@ -1090,12 +1205,13 @@ int run_uvt(const float *U, const float *V, const float *Xs, int n, int m, int d
         const int rpb = 16;
         hipLaunchKernelGGL(centre_vectors_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
                            sizeof(float) * 2 * (size_t)d, st, U, V, wf.colpart, merged ? (const float *)nullptr : wf.bar, n,
-                           m, d, rpb, wf.rm, wf.cm);
+                           m, d, rpb, wf.rm, wf.cm, (ws.tiled && al16 && xv && !(d == 128 && g_uvt_wpe128 == 3)) ? wf.vsplit : nullptr);
     }
     const float *Us = U + (int64_t)row0 * d;
     UvtWs w = ws;            // the slab's partial-sum arrays, with the full problem's centring vectors
     w.rm = wf.rm + row0;
     w.cm = wf.cm;
+    w.vsplit = (ws.tiled && al16 && xv && !(d == 128 && g_uvt_wpe128 == 3)) ? wf.vsplit : nullptr;
     const int nn = nrows;
     if (tiled) {
         if (d == 256) { const int rc = launch_tiled<256, 4, 32>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
