@@ -426,7 +426,7 @@ __device__ __forceinline__ void split_read_batch(f32x4 (&t)[4], unsigned abase, 
     switch (bi) {   // folded: bi is a constant in the unrolled caller
 #define MFCD_B(B) case B: lds_read16_issue<(4 * B + 0) * 1024>(t[0], abase); lds_read16_issue<(4 * B + 1) * 1024>(t[1], abase); \
                   lds_read16_issue<(4 * B + 2) * 1024>(t[2], abase); lds_read16_issue<(4 * B + 3) * 1024>(t[3], abase); break;
-        MFCD_B(0) MFCD_B(1) MFCD_B(2) MFCD_B(3)
+        MFCD_B(0) MFCD_B(1) MFCD_B(2) MFCD_B(3) MFCD_B(4) MFCD_B(5) MFCD_B(6) MFCD_B(7)
 #undef MFCD_B
     default: break;
     }
@@ -453,7 +453,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
                       double *__restrict__ part_err, double *__restrict__ part_xx)
 {
     constexpr int CPR = D / 4, PIECES = TC * D / 256, PPW = PIECES / NW, CMW = (TC + 63) / 64, PF = SPLIT ? 256 : 260;
-    static_assert(!SPLIT || (D % 32 == 0 && D <= 128 && PFX && XV), "split-product form: d in {32, 64, 128}, prefetch form");
+    static_assert(!SPLIT || (D % 32 == 0 && D <= 256 && PFX && XV), "split-product form: d in {32, 64, 128, 256}, prefetch form");
     static_assert(PIECES % NW == 0 && TC % 32 == 0 && CMW <= NW, "stage must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) float vts[2][PIECES * PF];   // [buffer][piece][256 + 4 pad]
     __shared__ __attribute__((aligned(16))) float cmss[2][CMW * 64];      // column means of U V^T, stage's columns
@@ -752,6 +752,25 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
 #endif
     };
 
+    if constexpr (PFX && TC == 32) {
+        // ONE tile per stage (d = 256): the two X register sets alternate from stage to stage (the loop is unrolled by
+        // two so that their roles stay fixed: no copy of a register whose load is still in flight)
+        auto one_stage = [&](int c0, f32x4 (&xq)[4], f32x4 (&xn)[4]) __attribute__((always_inline)) {
+            const float *cms = cmss[buf];
+            if (c0 + TC < c_end) issue_stage(c0 + TC, vts[buf ^ 1], cmss[buf ^ 1]);
+            if (active) tile(c0, c0 + TC < c_end ? c0 + TC : c0, 0, cms, xq, xn);
+            if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPend) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            buf ^= 1;
+        };
+#pragma unroll 1
+        for (int c0 = c_begin; c0 < c_end; c0 += 2 * TC) {
+            one_stage(c0, xa, xb);
+            if (c0 + TC >= c_end) break;
+            one_stage(c0 + TC, xb, xa);
+        }
+    } else {
     for (int c0 = c_begin; c0 < c_end; c0 += TC) {
         const float *cms = cmss[buf];
         MFCD_STAMP(td0);
@@ -764,7 +783,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
             if constexpr (PFX) {
                 // tiles in PAIRS, straight-line: the first uses xa and requests the second's values into xb, the second
                 // uses xb and requests the next pair's (or the next stage's first tile's) into xa — fixed roles, no copy
-                static_assert((TC / 32) % 2 == 0, "the X prefetch ping-pong needs an even number of tiles per stage");
+                static_assert((TC / 32) % 2 == 0 || TC == 32, "the X prefetch ping-pong needs an even number of tiles per stage");
 #pragma unroll 1
                 for (int j = 0; j < TC / 32; j += 2) {
                     const int cbA = c0 + 32 * j, cbB = cbA + 32;
@@ -796,6 +815,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
         cyc_sync += ts1 - ts0;
 #endif
         buf ^= 1;
+    }
     }
 #if MFCD_UVT_STAMPS
     if (lane == 0 && active) {
@@ -1030,7 +1050,7 @@ TiledCfg tiled_cfg(int d)
 }
 
 int g_uvt_split = 1;           // mfcd_set_tuning(MFCD_TUNE_UVT_SPLIT): 1 = bf16x3 split-product main kernel where it applies
-bool split_form_applies(int d) { return g_uvt_split != 0 && (d == 32 || d == 64 || d == 128); }
+bool split_form_applies(int d) { return g_uvt_split != 0 && (d == 32 || d == 64 || d == 128 || d == 256); }
 
 int g_uvt_target_wgs = 512;    // mfcd_set_tuning(MFCD_TUNE_UVT_TARGET_WGS): workgroups the tiled form aims for: one round of the chip (two
                                // per CU), then whatever the L2 rule below adds (C3: 617 us at 1024 workgroups, 639 us at 4096)
@@ -1089,7 +1109,7 @@ UvtWs plan_ws(char *base, int n, int m, int d)
     w.blk = (double *)take(sizeof(double) * 2 * (size_t)w.nblk);
     w.dummy_rows = (double *)take(sizeof(double) * 8 * (size_t)n);   // output the caller did not ask for (select entry)
     w.dummy_scal = (double *)take(sizeof(double) * 4);
-    // split-product form (d in {32, 64, 128}): 4 d bytes per V row like the fp32 table, rows padded to whole stages plus one
+    // split-product form (d in {32, 64, 128, 256}): 4 d bytes per V row like the fp32 table, rows padded to whole stages plus one
     // (the stage DMA never leaves the buffer)
     w.vsplit = nullptr;
     if (w.tiled && split_form_applies(d)) {
@@ -1109,7 +1129,7 @@ void launch_tiled_what(const UvtWs &w, const float *U, const float *V, const flo
 {
     const int row_blocks = (n + NW * 32 - 1) / (NW * 32);
     const unsigned blocks = (unsigned)row_blocks * (w.splits >= 8 ? 8u * ((w.splits + 7) / 8) : (unsigned)w.splits);
-    if constexpr (DD <= 128 && PFX) {
+    {
         if (xv && w.vsplit) {   // bf16x3 split product: V comes from the split table centre_vectors_kernel wrote
             hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, 2, true, WHAT, true>), dim3(blocks), dim3(NW * 64), 0, st, U,
                                (const float *)w.vsplit, X, w.rm, w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks,
