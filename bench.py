@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD (155 TF measured)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (task statement / same guide); the UV^T pass issues THREE bf16 products per fp32 product
 # Vector-issue roofline of the register-resident form (same guide, cycle constants): 256 CUs x 4 SIMD-32 at 2.4 GHz;
 # a wave64 VALU instruction occupies its SIMD for 2 cycles, a transcendental (v_rcp / v_sqrt) for 8.
 SIMDS, CLOCK_GHZ, CYC_PLAIN, CYC_TRANS = 1024, 2.4, 2, 8
@@ -399,11 +400,16 @@ def clock_ramp(runner, seconds, call_steps=20):
 
 
 def uvt_record(dev, U2, V2):
-    """Dense UV^T metric pass (mfcd_uvt_stats: fp32 MFMA, fused epilogue) timed with HIP events at C2, C3 and C5 sizes:
-    whole pass (every launch of the call, host syncs between groups of passes included), TFLOP/s = 2*n*m*d / time,
-    fraction of the fp32-MFMA peak."""
+    """Dense UV^T metric pass (mfcd_uvt_stats; d in {32, 64, 128, 256}: bf16x3 split product on the bf16 matrix pipe with fp32
+    accumulation, fused epilogue, X read once) timed with HIP events at C2, C3 and C5 sizes: whole pass (every launch of
+    the call, host syncs between groups of passes included).  Two rooflines beside each other: the X read against HBM
+    (4 n m bytes, the pass's only large operand) and the three bf16 products against the dense bf16 MFMA peak; the
+    nominal 2 n m d flops per second are kept for comparison with round 2's fp32-MFMA form (peak 157.3 TF)."""
     from mfcd import metrics
-    out = {"peak_TFLOPs": MFMA_F32_PEAK_TF, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "data": "synthetic (Gaussian X, U, V)"}
+    out = {"hbm_peak_GBps": HBM_PEAK_GBS, "mfma_bf16_peak_TFLOPs": MFMA_BF16_PEAK_TF, "mfma_f32_peak_TFLOPs": MFMA_F32_PEAK_TF,
+           "dtype": "f32 in / f32 out; products as three bf16 x bf16 -> f32 MFMAs (v_mfma_f32_32x32x16_bf16) on two-term "
+                    "bf16 expansions of U and V (16 significant bits each)",
+           "data": "synthetic (Gaussian X, U, V)"}
     shapes = [("C2", 4096, 4096, 64, 100), ("C3", 16384, 16384, 128, 10), ("C5", 100000, 20000, 256, 3)]   # passes per sync
     g = torch.Generator(device=dev).manual_seed(123)
     for name, n, m, d, reps in shapes:
@@ -436,18 +442,23 @@ def uvt_record(dev, U2, V2):
                     torch.cuda.synchronize()
                 return e0.elapsed_time(e1) * 1e3 / k, res
 
+            def fractions(us):
+                nominal = 2.0 * n * m * d / (us * 1e-6) / 1e12
+                xgb = 4.0 * n * m / (us * 1e-6) / 1e9
+                return {"pass_us": round(us, 1), "nominal_TFLOPs": round(nominal, 1),
+                        "x_read_GBps": round(xgb, 1), "frac_of_hbm_peak": round(xgb / HBM_PEAK_GBS, 4),
+                        "issued_bf16_TFLOPs": round(3 * nominal, 1),
+                        "frac_of_bf16_mfma_peak": round(3 * nominal / MFMA_BF16_PEAK_TF, 4),
+                        "vs_f32_mfma_peak": round(nominal / MFMA_F32_PEAK_TF, 4)}
+
             us, (rs, sc) = timed(3)
-            tf = 2.0 * n * m * d / (us * 1e-6) / 1e12
-            out[name] = {"n": n, "m": m, "d": d, "pass_us": round(us, 1), "TFLOPs": round(tf, 1),
-                         "frac_of_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TF, 4),
-                         "x_read_GBps": round(4.0 * n * m / (us * 1e-6) / 1e9, 1),
-                         "finite": bool(torch.isfinite(sc[:2]).all().item())}
+            out[name] = dict({"n": n, "m": m, "d": d}, **fractions(us))
+            out[name]["finite"] = bool(torch.isfinite(sc[:2]).all().item())
             # the passes the two metric functions actually issue: rows only (compute_alpha_and_norm_ratios) and
             # global error only (compute_reconstruction_error), mfcd_uvt_stats_select
             for what, key in ((1, "rows_only"), (2, "error_only")):
                 usw, _ = timed(what)
-                out[name][key] = {"pass_us": round(usw, 1),
-                                  "frac_of_mfma_f32_peak": round(2.0 * n * m * d / (usw * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)}
+                out[name][key] = fractions(usw)
             del X
             torch.cuda.empty_cache()
         except Exception as e:   # a box with less free memory still reports the smaller shapes

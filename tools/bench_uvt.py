@@ -39,9 +39,12 @@ for name, n, m, d in [("C1", 256, 256, 8), ("C2", 4096, 4096, 64), ("C3", 16384,
             M = U @ V.t(); M -= M.mean(0, keepdim=True); e = torch.norm(M - X) / torch.norm(X)
         torch.cuda.synchronize()
         dt_t = (time.perf_counter() - t1) / reps
-    print(f"{name}: n={n} m={m} d={d}  uvt_stats {dt*1e6:9.1f} us  = {flops/dt/1e12:6.2f} TFLOP/s ({flops/dt/157.3e12*100:5.1f}% of 157.3 TF fp32 MFMA)"
-          f"  X traffic {bytes_/dt/1e9:7.1f} GB/s ({bytes_/dt/8e12*100:4.1f}% of 8 TB/s) | rows-only {sel['rows']*1e6:8.1f} us "
-          f"({flops/sel['rows']/157.3e12*100:4.1f}%), error-only {sel['err']*1e6:8.1f} us ({flops/sel['err']/157.3e12*100:4.1f}%)"
+    split = d in (32, 64, 128, 256)      # bf16x3 split-product form (three bf16 MFMAs per fp32 product)
+    pipe = (f"{3*flops/dt/1e12:7.1f} bf16 TFLOP/s issued ({3*flops/dt/2500e12*100:4.1f}% of the 2.5 PF bf16 MFMA peak)" if split
+            else f"{flops/dt/157.3e12*100:5.1f}% of the 157.3 TF fp32 MFMA peak")
+    print(f"{name}: n={n} m={m} d={d}  uvt_stats {dt*1e6:9.1f} us  = {flops/dt/1e12:6.2f} nominal TFLOP/s; {pipe}"
+          f"; X read {bytes_/dt/1e9:7.1f} GB/s ({bytes_/dt/8e12*100:4.1f}% of 8 TB/s) | rows-only {sel['rows']*1e6:8.1f} us "
+          f"({bytes_/sel['rows']/8e12*100:4.1f}% HBM), error-only {sel['err']*1e6:8.1f} us ({bytes_/sel['err']/8e12*100:4.1f}% HBM)"
           f" | torch-op sequence on the same GPU {dt_t*1e6:9.1f} us", flush=True)
     del U, V, X
     torch.cuda.empty_cache()
