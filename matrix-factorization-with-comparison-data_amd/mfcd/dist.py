@@ -419,8 +419,83 @@ def reconstruction_error_sharded(U, V, X_rows, row0, s, group=None, slab_pass=hi
     return float(np.sqrt(e2) / np.sqrt(r2)) if r2 > 0 else float("nan") if e2 == 0 else float("inf")   # as metrics.reconstruction_error
 
 
-def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
-    """bench.py's N>1 leg: weak scaling, per-rank batch cfg['B'], global batch B*world; returns the JSON dict."""
+def _probe_dp_phases(binding, stream, B, nsteps, sharded):
+    """Per-phase split of one multi-GPU optimiser step, measured with HIP event pairs over `nsteps` steps of the SPLIT
+    form of the loop (the same kernels and the same collective the native loop enqueues, issued phase by phase from
+    Python so that events fit between them): coefficient / pack kernel, collective, fused step.  Untimed region of the
+    benchmark; the model advances by nsteps steps on every rank alike.  → dict of mean microseconds per phase."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = stream.device
+    ev = lambda: torch.cuda.Event(enable_timing=True)                  # noqa: E731
+    marks = []
+    if sharded:
+        shard = RowShard(binding, rank, world)
+        comp = HipShardCompute(shard)
+        xbuf, terms = comp.new_xbuf(B), torch.empty(B, dtype=torch.float32, device=dev)
+        hyper = binding.hyper()
+        for k in range(nsteps):
+            batch = stream[k * B:(k + 1) * B]
+            e = [ev() for _ in range(4)]
+            e[0].record(); comp.pack(batch, B, xbuf)
+            e[1].record(); dist.all_reduce(xbuf.view(torch.int32), op=dist.ReduceOp.SUM)
+            e[2].record(); comp.apply(batch, B, xbuf, binding.step + k + 1, hyper, terms)
+            e[3].record(); marks.append(e)
+        binding.advance(nsteps)
+        shard.gather()
+        names = ("pack_us", "collective_us", "step_us")
+    else:
+        comp = HipCompute(binding)
+        Bg = B * world
+        mine = torch.zeros((2, B), dtype=torch.float32, device=dev)
+        gathered = torch.empty(world * 2 * B, dtype=torch.float32, device=dev)
+        g_all = torch.empty(Bg, dtype=torch.float32, device=dev)
+        for k in range(nsteps):
+            lo, hi = k * Bg, (k + 1) * Bg
+            e = [ev() for _ in range(4)]
+            e[0].record(); comp.coefficients(stream[lo + rank * B: lo + (rank + 1) * B], Bg, out=mine)
+            e[1].record(); dist.all_gather_into_tensor(gathered, mine.view(-1))
+            e[2].record()
+            g_all.view(world, B).copy_(gathered.view(world, 2, B)[:, 0, :])
+            comp.apply(stream[lo:hi], g_all)
+            e[3].record(); marks.append(e)
+        names = ("coefficients_us", "collective_us", "step_us")
+    torch.cuda.synchronize()
+    tail = marks[len(marks) // 4:]                                      # first quarter: warm-up of the split path
+    out = {nm: round(sum(e[i].elapsed_time(e[i + 1]) for e in tail) * 1e3 / len(tail), 2) for i, nm in enumerate(names)}
+    out["sum_us"] = round(sum(out.values()), 2)
+    out["steps_probed"] = len(tail)
+    out["how"] = ("HIP event pairs around each phase of the per-step loop issued from Python (same kernels, same collective "
+                  "as the native loop; gaps between phases include the Python issue time)")
+    return out
+
+
+def _dp_cost_model(cfg, world, sharded):
+    """What one optimiser step of the multi-GPU form should cost on one node, from single-GPU measurements and the
+    guide's xGMI figures: kernel times measured on one MI355X, collective = RCCL small-message latency
+    (ring over xGMI, latency-bound at these sizes: the payload is 512 B per rank, or 3*B*d*4 bytes for the row exchange)."""
+    elems = (cfg["n"] + cfg["m"]) * cfg["d"]
+    sweep_us = 24.0 * elems / 6.0e6                 # fused streaming step: 24 B/element at ~6 TB/s
+    if sharded:
+        coll_us = 12.0 + 2.0 * max(0, world.bit_length() - 1) + 3 * cfg["B"] * cfg["d"] * 4 / 50e3   # all-reduce of <= 192 rows
+        per_step = {"pack_us": 3.0, "collective_us": round(coll_us, 1), "step_us": round(max(2.5, sweep_us / world), 1)}
+        samples = cfg["B"]
+    else:
+        coll_us = 10.0 + 2.0 * max(0, world.bit_length() - 1)                                         # all-gather of 512 B per rank
+        per_step = {"coefficients_us": 2.5, "collective_us": round(coll_us, 1), "step_us": round(max(3.0, sweep_us), 1)}
+        samples = cfg["B"] * world
+    tot = sum(per_step.values())
+    return {"per_step_us": per_step, "sum_us": round(tot, 1), "predicted_value": round(samples / tot * 1e6, 1),
+            "note": "strictly serial chain kernel -> collective -> kernel per optimiser step (no overlap is possible inside "
+                    "a step: the step reads what the collective delivers, and the next step's first kernel reads what this "
+                    "step writes); the single-GPU register-resident form takes 0.55 us per 64-sample step at C2, so at C2 no "
+                    "per-step collective can beat one GPU — the multi-GPU forms pay off where the state does not fit one "
+                    "GPU's registers (C4: 32 us per step on one GPU)"}
+
+
+def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native", extras=True):
+    """bench.py's N>1 leg: weak scaling, per-rank batch cfg['B'], global batch B*world; returns the JSON dict.
+    extras: also probe the per-phase split, attach the cost model and (C2 headline) a `c4` sub-record — BASELINE
+    configs[3], the configuration named for 8-GPU data parallelism — in both multi-GPU forms."""
     import time
 
     import numpy as np
@@ -494,6 +569,16 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
     dt = float(dt.item())
     if sharded:
         native.gather()
+    phases = None
+    if extras and mode in ("native", "allgather", "shard"):
+        probe_steps = 48
+        order = train.ordered(torch.randperm(train.N, generator=gen))
+        if order.shape[0] >= probe_steps * Bg:
+            if sharded and native is not None and native.shard is not None:
+                native.gather()
+            phases = _probe_dp_phases(binding, order[: probe_steps * Bg], B, probe_steps, sharded)
+            if sharded and native is not None and native.shard is not None:
+                native.shard = RowShard(binding, rank, world)          # the probe moved the full tensors on
     # replicas must still agree bit for bit
     chk = torch.stack([model.U.data.double().sum(), model.V.data.double().sum()])
     lo_, hi_ = chk.clone(), chk.clone()
@@ -508,7 +593,7 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
             "shard": "row-sharded state in libmfcd_hip.so: one RCCL all-reduce of the batch's <= 192 rows per optimiser "
                      "step, global batch 64, results equal to one GPU"}[mode]
     abytes = bench_mod.algorithmic_bytes_per_step(dict(cfg, B=Bg))
-    return {
+    out = {
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3 / steps, 6),
         "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32",
@@ -517,7 +602,7 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
                                f"random triplets, {'global' if sharded else 'per-GPU'} batch 64, Adam lr=1e-3 wd=1e-5, "
                                "validation pass per epoch",
                    "global_batch": Bg, "train_samples": train.N,
-                   "parallelism": f"dp{world} ({what})",
+                   "parallelism": f"dp{world} ({what})", "multi_gpu_form": mode,
                    "replicas_in_sync": in_sync},
         "roofline": {"bound": "hbm", "achieved": round(abytes / (dt / steps) / 1e9, 1), "peak": bench_mod.HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(abytes / (dt / steps) / 1e9 / bench_mod.HBM_PEAK_GBS, 4),
@@ -526,3 +611,23 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native"):
                               if sharded else
                               "per-GPU step period including the collective; every rank streams the full replicated state")},
     }
+    if extras:
+        out["phase_split"] = phases
+        out["cost_model"] = _dp_cost_model(cfg, world, sharded)
+        if cfg.get("name", "C2") == "C2":
+            # BASELINE configs[3] (C4: 65536^2, d = 64, K = 4) beside the headline, in both multi-GPU forms: short runs
+            c4 = dict(bench_mod.C4, name="C4")
+            sub = {}
+            for form in (("native", "shard") if mode != "allgather" else ("allgather",)):
+                try:
+                    r = bench_data_parallel(c4, dev, 200, 20, seed, mode=form, extras=False)
+                    sub[form] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling")}
+                    sub[form]["global_batch"] = r["config"]["global_batch"]
+                    sub[form]["replicas_in_sync"] = r["config"]["replicas_in_sync"]
+                    cm = _dp_cost_model(c4, world, form == "shard")
+                    sub[form]["cost_model"] = {k: cm[k] for k in ("per_step_us", "sum_us", "predicted_value")}
+                except Exception as e:       # the headline stands on its own
+                    sub[form] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            out["c4"] = {"workload": "BASELINE configs[3]: n=m=65536, d=64, p=0.0005, K=4 (3.4 M training samples), "
+                                     "8-GPU data parallel", "forms": sub}
+    return out
