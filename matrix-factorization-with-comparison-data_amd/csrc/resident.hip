@@ -202,13 +202,6 @@ struct InlineStage {
 
 size_t train_inline_stage_bytes() { return (size_t)kInlineStageUnits * 16; }
 
-__device__ __forceinline__ void event_append(unsigned *__restrict__ ev_cnt, uint4 *__restrict__ ev_ent, size_t list,
-                                             const uint4 &e)
-{
-    const unsigned slot = atomicAdd(ev_cnt + list, 1u);
-    if (slot < (unsigned)kEventCap - 1u) ev_ent[list * kEventCap + slot] = e;   // a usable list holds <= 63 entries
-}
-
 template <bool INLINE>
 __global__ __launch_bounds__(256) void train_prologue_kernel(InlineStage inl, const uint4 *__restrict__ stage_host,
                                                              uint4 *__restrict__ stage_dev, int stage_units,
@@ -241,12 +234,17 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(InlineStage inl, co
                             (unsigned)(s.j - w[2] * rows_per_wave)};
     const int c = k >> tshift;
     const bool copy_back = c > 0 && (k & ((1 << tshift) - 1)) < look;
+    // one entry per distinct owner wave of the sample; all list slots are requested first (independent returning
+    // atomics in flight together), the entries are stored once the slots are known
+    uint4 e[3];
+    size_t list[3];
+    bool need[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        bool first = true;                     // one entry per distinct owner wave of the sample
+        bool first = true;
 #pragma unroll
         for (int r2 = 0; r2 < r; ++r2) first = first && w[r2] != w[r];
-        if (!first) continue;
+        need[r] = first;
         unsigned own = 0u, rows = 0u;
 #pragma unroll
         for (int r2 = r; r2 < 3; ++r2)
@@ -254,10 +252,21 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(InlineStage inl, co
                 own |= 1u << r2;
                 rows |= lr[r2] << (10 * r2);
             }
-        const uint4 e = make_uint4(((unsigned)k << 9) | (tl << 3) | own, rows, __float_as_uint(s.z), 0u);
-        const size_t list = (size_t)w[r] * (size_t)nch_cap + (size_t)c;
-        event_append(ev_cnt, ev_ent, list, e);
-        if (copy_back) event_append(ev_cnt, ev_ent, list - 1, e);
+        e[r] = make_uint4(((unsigned)k << 9) | (tl << 3) | own, rows, __float_as_uint(s.z), 0u);
+        list[r] = (size_t)w[r] * (size_t)nch_cap + (size_t)c;
+    }
+    unsigned slot[3] = {0u, 0u, 0u}, slot_back[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (need[r]) slot[r] = atomicAdd(ev_cnt + list[r], 1u);
+        if (need[r] && copy_back) slot_back[r] = atomicAdd(ev_cnt + list[r] - 1, 1u);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        // an entry that finds its list full is dropped: the count says so and the wave takes the generic loop
+        if (need[r] && slot[r] < (unsigned)kEventCap - 1u) ev_ent[list[r] * kEventCap + slot[r]] = e[r];
+        if (need[r] && copy_back && slot_back[r] < (unsigned)kEventCap - 1u)
+            ev_ent[(list[r] - 1) * kEventCap + slot_back[r]] = e[r];
     }
 }
 
