@@ -195,6 +195,9 @@ ResidentPlan plan_resident(int64_t N, int B, int n, int m, int d, int num_cus, b
 //      an entry that finds its list full is dropped and the count says so (the wave then takes the generic loop).
 // INLINE: the table travels in the kernel-argument segment itself (first parameter, so it sits at offset 0 of the
 // segment, which every lane can address); short calls then need no read over the host link at all.
+#ifndef MFCD_PROLOGUE_THREADS
+#define MFCD_PROLOGUE_THREADS 64
+#endif
 constexpr int kInlineStageUnits = 232;   // 16-byte units: ResidentCold (8) + 224 step scalars; 3712 bytes of kernarg
 struct InlineStage {
     uint4 v[kInlineStageUnits];
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(InlineStage inl, co
                                                              int64_t nch_cap, mfcd_sample *__restrict__ xs,
                                                              unsigned *__restrict__ ev_cnt, uint4 *__restrict__ ev_ent)
 {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < stage_units) {
         if constexpr (INLINE) {
             const uint4 *ka = (const uint4 *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -276,16 +279,19 @@ int launch_train_prologue(const void *stage_host, const void *stage_host_devview
 {
     const int units = (int)((stage_bytes + 15) / 16);
     const int64_t items = xs ? (N > units ? N : units) : units;
-    const dim3 grid((unsigned)((items + 255) / 256));
+    // 64-thread workgroups: the kernel is a chain of dependent round trips per thread (record load, returning atomics,
+    // entry stores), so it wants many workgroups per CU in flight, not few wide ones
+    constexpr int kPT = MFCD_PROLOGUE_THREADS;
+    const dim3 grid((unsigned)((items + kPT - 1) / kPT));
     if (units <= kInlineStageUnits) {
         InlineStage inl;
         std::memcpy(inl.v, stage_host, (size_t)units * 16);
-        hipLaunchKernelGGL(train_prologue_kernel<true>, grid, dim3(256), 0, st, inl, (const uint4 *)nullptr,
+        hipLaunchKernelGGL(train_prologue_kernel<true>, grid, dim3(kPT), 0, st, inl, (const uint4 *)nullptr,
                            (uint4 *)stage_dev, units, samples, N, B, n, m, rows_per_wave, tshift, look, nch_cap, xs,
                            ev_cnt, (uint4 *)ev_ent);
     } else {
         static const InlineStage none{};
-        hipLaunchKernelGGL(train_prologue_kernel<false>, grid, dim3(256), 0, st, none, (const uint4 *)stage_host_devview,
+        hipLaunchKernelGGL(train_prologue_kernel<false>, grid, dim3(kPT), 0, st, none, (const uint4 *)stage_host_devview,
                            (uint4 *)stage_dev, units, samples, N, B, n, m, rows_per_wave, tshift, look, nch_cap, xs,
                            ev_cnt, (uint4 *)ev_ent);
     }
