@@ -38,6 +38,9 @@ def short(name):
     return m.group(1) if m else name[:60]
 
 
+if not glob.glob(f"{E}/prof_uvt/runc/*_kernel_trace.csv"):
+    print("(no UV^T kernel trace kept: the per-pass split is skipped)")
+    sys.exit(0)
 rows = list(csv.DictReader(open(newest(f"{E}/prof_uvt/runc/*_kernel_trace.csv"))))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 passes, cur = [], []

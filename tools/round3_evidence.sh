@@ -28,7 +28,7 @@ if [ "$1" = "prof" ]; then
 $P --stats -d $E/prof_driver -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $E/bench_c2_driver_cmd_under_rocprof.json 2>/dev/null
 $P --stats -d $E/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-extras > $E/bench_c2_under_rocprof.json 2>/dev/null
 $P --stats -d $E/prof_c3 -- python3 $R/bench.py --workload C3 --steps 3356 --warmup 1678 --no-cpu-baseline --no-extras > /dev/null 2>&1
-MFCD_SKIP_TORCH=1 UVT_BENCH_SECONDS=0.04 $P --stats -d $E/prof_uvt -- python3 $R/tools/bench_uvt.py C2 C3 C5 > /dev/null 2>&1
+MFCD_SKIP_TORCH=1 UVT_BENCH_SECONDS=0.01 $P --stats -d $E/prof_uvt -- python3 $R/tools/bench_uvt.py C2 C3 C5 > /dev/null 2>&1
 fi
 if [ "$1" = "pmc" ]; then
 B="python3 $R/bench.py --no-cpu-baseline --no-extras --clock-ramp 0 --steps 2098 --warmup 1049"
@@ -47,6 +47,6 @@ for tag in c2 c3; do python3 tools/pmc_summary.py $E/pmc_${tag}_a resident_train
 python3 tools/pmc_summary.py $E/pmc_uvt_sq uvt_tiled_kernel > $E/uvt_pmc.txt; python3 tools/pmc_summary.py $E/pmc_uvt_fetch uvt_tiled_kernel >> $E/uvt_pmc.txt
 cat $E/resident_pmc_c2.txt $E/uvt_pmc.txt
 fi
-find $E -name "*kernel_trace.csv" -size +6M -delete || true
+find $E -name "*kernel_trace.csv" -size +6M -not -path "*prof_uvt*" -delete || true
 find $E -name "*counter_collection.csv" -size +6M -delete || true
 du -sh $E
