@@ -136,6 +136,7 @@ int mfcd_set_resident_math(int fast);
 #define MFCD_TUNE_STREAM_CHUNKS 8       /* streaming form: 16-byte chunks per thread and array; 0 = auto      */
 #define MFCD_TUNE_UVT_TARGET_WGS 9      /* UV^T pass: workgroups the column split aims for (default 512)       */
 #define MFCD_TUNE_UVT_SPLIT 11          /* UV^T pass, d in {32, 64, 128}: 1 (default) = bf16x3 split product on the bf16 matrix pipe, 0 = fp32 MFMA */
+#define MFCD_TUNE_RANK_SORT 12          /* Spearman kernel's sort: 1 (default) = block radix sort, 0 = bitonic network in LDS */
 #define MFCD_TUNE_UVT_MIN_STAGES 10     /* UV^T pass: column stages a workgroup sweeps at least (default 8)    */
 int mfcd_set_tuning(int key, int64_t value);
 

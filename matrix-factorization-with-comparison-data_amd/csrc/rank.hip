@@ -18,6 +18,10 @@
 //     centred ranks (|2 rank - (m+1)| <= m, sums <= 4 m^3 < 2^46), reduced in fixed order; rho is formed in f64.
 // The result is therefore independent of thread scheduling and equals scipy's float64 computation to rounding.
 // LDS: 8 m bytes (156 KiB at m = 20000).  Rows longer than 20448 are not handled here (host: torch ops).
+#include <cstring>
+
+#include <rocprim/block/block_radix_sort.hpp>
+
 #include "common.h"
 
 namespace {
@@ -116,7 +120,113 @@ __global__ __launch_bounds__(kRankThreads) void spearman_rows_kernel(const float
         rho[r] = Snan != 0 ? __longlong_as_double(0x7ff8000000000000ll) : (double)Sxy / (sqrt((double)Saa) * sqrt((double)Sxx));
 }
 
+
+// Round 3: the same kernel with the sort done by a block-wide LSD RADIX sort (rocPRIM's block_radix_sort: keys and
+// column indices in registers, IPT per thread, digits ranked with wave-level match operations, exchanged through LDS)
+// instead of the 120-stage bitonic network through LDS: ~5x fewer instructions per element at m = 20000.  Everything
+// after the sort — average ranks per run of equal keys, exact 64-bit sums, NaN propagation — is the code above.
+// LDS: [sort storage, then sorted keys (4 m) + columns (2 m)] + A's doubled ranks by column (2 m).
+template <int IPT>
+__global__ __launch_bounds__(kRankThreads) void spearman_rows_radix_kernel(const float *__restrict__ A, int64_t lda,
+                                                                           const float *__restrict__ X, int64_t ldx,
+                                                                           int m, int region0, double *__restrict__ rho)
+{
+    using sort_t = rocprim::block_radix_sort<unsigned, kRankThreads, IPT, unsigned short>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typename sort_t::storage_type &storage = *reinterpret_cast<typename sort_t::storage_type *>(smem);
+    unsigned *key = reinterpret_cast<unsigned *>(smem);                        // [m]   (after the sort)
+    unsigned short *idx = reinterpret_cast<unsigned short *>(key + m);          // [m]
+    unsigned short *ra2 = reinterpret_cast<unsigned short *>(smem + region0);   // [m] doubled rank of A by column
+    __shared__ long long red[kRankThreads / 64];
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const long long centre = (long long)m + 1;     // 2 * mean rank
+    long long saa = 0, sxx = 0, sxy = 0;
+    int has_nan = 0;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const float *row = pass == 0 ? A + r * lda : X + r * ldx;
+        unsigned k[IPT];
+        unsigned short c[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {                  // striped (coalesced) load: any arrangement may enter a sort
+            const int p = j * kRankThreads + tid;
+            k[j] = 0xFFFFFFFFu;                          // padding sorts last
+            c[j] = (unsigned short)0xFFFF;
+            if (p < m) {
+                const float f = row[p];
+                has_nan |= (f != f);
+                k[j] = sortable_key(f);
+                c[j] = (unsigned short)p;
+            }
+        }
+        __syncthreads();                                 // the previous pass's key / idx readers are done
+        sort_t().sort(k, c, storage);                    // -> blocked arrangement: thread t holds positions t*IPT ..
+        __syncthreads();                                 // the sort's storage becomes the sorted arrays
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int p = tid * IPT + j;
+            if (p < m) {
+                key[p] = k[j];
+                idx[p] = c[j];
+            }
+        }
+        __syncthreads();
+        long long s_own = 0, s_xy = 0;
+        for (int p = tid; p < m; p += kRankThreads) {
+            const unsigned kp = key[p];
+            if (p > 0 && key[p - 1] == kp) continue;            // not the first element of its run
+            int e = p;
+            while (e + 1 < m && key[e + 1] == kp) ++e;
+            const long long c2 = (long long)(p + e + 2) - centre;   // doubled, centred average rank of the run
+            s_own += c2 * c2 * (long long)(e - p + 1);
+            if (pass == 0) {
+                for (int q = p; q <= e; ++q) ra2[idx[q]] = (unsigned short)(p + e + 2);
+            } else {
+                for (int q = p; q <= e; ++q) s_xy += c2 * ((long long)ra2[idx[q]] - centre);
+            }
+        }
+        if (pass == 0) saa = s_own;
+        else { sxx = s_own; sxy = s_xy; }
+    }
+    const long long Saa = block_sum_i64(saa, red), Sxx = block_sum_i64(sxx, red), Sxy = block_sum_i64(sxy, red);
+    const long long Snan = block_sum_i64((long long)has_nan, red);
+    if (tid == 0)
+        rho[r] = Snan != 0 ? __longlong_as_double(0x7ff8000000000000ll) : (double)Sxy / (sqrt((double)Saa) * sqrt((double)Sxx));
+}
+
+template <int IPT>
+int launch_radix(const float *A, int64_t lda, const float *X, int64_t ldx, int rows, int m, double *rho, hipStream_t st)
+{
+    using sort_t = rocprim::block_radix_sort<unsigned, kRankThreads, IPT, unsigned short>;
+    size_t region0 = sizeof(typename sort_t::storage_type);
+    if (region0 < (size_t)m * 6) region0 = (size_t)m * 6;
+    region0 = (region0 + 15) & ~(size_t)15;
+    const size_t lds = region0 + (size_t)m * 2;
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)spearman_rows_radix_kernel<IPT>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed = lds;
+    }
+    hipLaunchKernelGGL(spearman_rows_radix_kernel<IPT>, dim3((unsigned)rows), dim3(kRankThreads), lds, st, A, lda, X, ldx, m,
+                       (int)region0, rho);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int g_rank_sort = 1;   // 1 = radix (default), 0 = bitonic network (mfcd_set_tuning(MFCD_TUNE_RANK_SORT))
+
 }  // namespace
+
+namespace mfcd_detail {
+int set_rank_sort(int v)
+{
+    if (v != 0 && v != 1) return MFCD_EINVAL;
+    g_rank_sort = v;
+    return 0;
+}
+}  // namespace mfcd_detail
 
 extern "C" int mfcd_spearman_max_columns(void) { return kRankMaxCols; }
 
@@ -126,6 +236,11 @@ extern "C" int mfcd_spearman_rows(const float *A, int64_t lda, const float *X, i
     if (!A || !X || !rho || rows < 0 || m <= 0 || lda < m || ldx < m) return MFCD_EINVAL;
     if (m > kRankMaxCols) return MFCD_EINVAL;
     if (rows == 0) return 0;
+    if (g_rank_sort == 1) {
+        if (m <= 4 * kRankThreads) return launch_radix<4>(A, lda, X, ldx, rows, m, rho, (hipStream_t)stream);
+        if (m <= 8 * kRankThreads) return launch_radix<8>(A, lda, X, ldx, rows, m, rho, (hipStream_t)stream);
+        return launch_radix<20>(A, lda, X, ldx, rows, m, rho, (hipStream_t)stream);
+    }
     int P = 2;
     while (P < m) P <<= 1;
     const size_t lds = (size_t)m * 8;

@@ -658,6 +658,7 @@ extern "C" int mfcd_set_tuning(int key, int64_t value)
             return 0;
         case MFCD_TUNE_UVT_WPE128: return mfcd_detail::set_uvt_wpe128((int)value);
         case MFCD_TUNE_UVT_SPLIT: return mfcd_detail::set_uvt_split((int)value);
+        case MFCD_TUNE_RANK_SORT: return mfcd_detail::set_rank_sort((int)value);
         case MFCD_TUNE_UVT_TARGET_WGS: return mfcd_detail::set_uvt_target_wgs((int)value);
         case MFCD_TUNE_UVT_MIN_STAGES: return mfcd_detail::set_uvt_min_stages((int)value);
         case MFCD_TUNE_STREAM_CHUNKS:

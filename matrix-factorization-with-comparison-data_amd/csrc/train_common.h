@@ -166,6 +166,7 @@ extern int g_resident_math;
 
 int set_uvt_wpe128(int v);   // uvt.hip
 int set_uvt_split(int v);    // uvt.hip
+int set_rank_sort(int v);    // rank.hip
 int set_uvt_target_wgs(int v);   // uvt.hip
 int set_uvt_min_stages(int v);   // uvt.hip
 

@@ -65,7 +65,7 @@ SIGNATURES = {
 
 TUNE_KEYS = {"resident_q": 1, "resident_wpc": 2, "resident_lookahead": 3, "resident_lds_pad": 4,
              "resident_spin_limit": 5, "short_call_steps": 6, "uvt_wpe128": 7, "stream_chunks": 8,
-             "uvt_target_wgs": 9, "uvt_min_stages": 10, "uvt_split": 11}
+             "uvt_target_wgs": 9, "uvt_min_stages": 10, "uvt_split": 11, "rank_sort": 12}
 
 
 class TrainPlan(ctypes.Structure):
