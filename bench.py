@@ -656,6 +656,7 @@ def _run(args):
             "step_form": splan["form_name"],
             "roofline": roofline_record(cfg, splan, ev_us, (kavg, kmin, kmax), kernel_step_us=None if bf16 else kavg)}
         out["uvt"] = uvt_record(dev, runner.model.U.data, runner.model.V.data)
+    runner.bind.flush()     # (the Adam step counters were deferred; ADVICE r2: never leave them stale)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.seed)
     return out, True
