@@ -187,6 +187,7 @@ class Runner:
         self.stream, self.pos = None, 0
         self.pre = engine.StreamPrefetch(dev)   # next epoch's record stream is built under the running step kernel
         self.train_events = []  # (start, stop, launches) around each fused-step call in the timed region
+        self.launched = []      # events behind the last two enqueued calls on the measured model
         # the workspace is planned ONCE for an epoch (as engine.fit does): no call of the run re-plans or re-initialises it
         engine.reserve_workspace(self.train.N, cfg["B"], cfg["n"], cfg["m"], cfg["d"], dev)
         self.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(64)]
@@ -225,12 +226,30 @@ class Runner:
             if record:
                 e1.record()
                 self.train_events.append((e0, e1, take))
+            # an event behind each enqueued call on the workspace (whichever model it stepped): a staged prologue writes the
+            # set of regions that the call BEFORE the most recent one may still be reading.  Short calls record none (the
+            # driver's 20-step region stays free of it); a stage after one then waits for everything enqueued so far
+            ev = None
+            if take >= 256:
+                ev = self.launched[0] if len(self.launched) == 2 and self.launched[0] is not None else torch.cuda.Event()
+                ev.record()
+            self.launched = (self.launched + [ev])[-2:]
             consumed += hi - lo
             self.pos += take
             steps -= take
             if self.pos == self.steps_per_epoch and self.pre.pending is None:
-                # the epoch's last steps are enqueued: start building the next epoch's stream underneath them
-                self.pre.start(self.train, torch.randperm(self.train.N, generator=self.gen))
+                # the epoch's last steps are enqueued: start building the next epoch's stream underneath them, and stage
+                # the prologue of the call that will consume it (as mfcd.engine.fit does); if the next call turns out
+                # not to be that whole epoch, the staged prologue is simply not used
+                nxt = self.loss_bufs.get(self.steps_per_epoch)
+                stage = None
+                if bind is self.bind and nxt is not None:
+                    stage = lambda rec, side: self.engine.stage_next_call(bind, rec, B, nxt, side)   # noqa: E731
+                after = self.launched[0] if len(self.launched) == 2 else None
+                if len(self.launched) == 2 and after is None:
+                    after = torch.cuda.Event()
+                    after.record()
+                self.pre.start(self.train, torch.randperm(self.train.N, generator=self.gen), after=after, stage=stage)
             if self.pos == self.steps_per_epoch:  # structure.py:858-868
                 self.engine.eval_batches(self.model.U.data, self.model.V.data, self.val.dev, B)
                 self.stream = None

@@ -219,6 +219,17 @@ int mfcd_train_call_prepare(void *U, void *V, float *mU, float *vU, float *mV, f
                             double weight_decay, void *workspace, size_t workspace_bytes, void **handle_out);
 int mfcd_train_call_run(void *handle, const mfcd_sample *samples, int64_t N, int64_t step0, float *loss_per_step,
                         void *stream);
+/*
+ * Stage a LATER call of the same handle: run its prologue (stage table, sample translation, per-wave event lists of the
+ * resident form) NOW on `side_stream`, into the workspace's second set of prologue regions, so that it overlaps the step
+ * kernel of the call that is running.  The matching mfcd_train_call_run (same samples, N, step0, loss_per_step) then
+ * launches its step kernel only.  The CALLER orders the streams: `side_stream` must not start this before the launch
+ * two calls back has finished (it used the same set), and the main stream must wait for `side_stream` before the
+ * matching run.  A no-op (returns 0) for calls that would not take the resident look-ahead form; a staged prologue that
+ * is never run is simply overwritten by the next one.
+ */
+int mfcd_train_call_stage(void *handle, const mfcd_sample *samples, int64_t N, int64_t step0, float *loss_per_step,
+                          void *side_stream);
 int mfcd_train_call_release(void *handle);
 
 /*

@@ -465,6 +465,10 @@ struct TrainLayout {
     size_t dbg_off, stage_off, stage_bytes, terms_off, evcnt_off, evcnt_bytes, event_off, event_bytes;
     size_t ualt_off, valt_off, xs_off, mailbox_off, mailbox_bytes, total;
     size_t alt_end;  // end of the streaming members of the union (U_alt, V_alt)
+    // second set of the regions the prologue kernel writes (stage table, list counters, list entries, translated samples):
+    // a call's prologue may be STAGED on a side stream under the previous call's step kernel (mfcd_train_call_stage)
+    size_t stage2_off, evcnt2_off, event2_off, xs2_off;
+    bool two_sets;
     int64_t K_cap;
     int64_t nch_cap;                    // chunks per wave of the event lists
     mfcd_detail::ResidentEvents ev;     // geometry of the event lists (tshift 0: none)
@@ -526,6 +530,16 @@ TrainLayout train_layout(int64_t N_cap, int B, int n, int m, int d)
     }
     L.alt_end = a_off;
     L.total = a_off > b_off ? a_off : b_off;
+    L.two_sets = L.resident && L.ev.tshift != 0;
+    L.stage2_off = L.evcnt2_off = L.event2_off = L.xs2_off = 0;
+    if (L.two_sets) {
+        size_t c = align256(L.total);
+        L.stage2_off = c; c += align256(L.stage_bytes);
+        L.evcnt2_off = c; c += align256(L.evcnt_bytes);
+        L.event2_off = c; c += align256(L.event_bytes);
+        L.xs2_off = c; c += align256(sizeof(mfcd_sample) * (size_t)Nc);
+        L.total = c;
+    }
     return L;
 }
 
@@ -555,6 +569,18 @@ struct WsState {
     int B = 0, n = 0, m = 0, d = 0;
     TrainLayout L{};
     unsigned launch_id = 0;    // resident launches so far (mod kMaxLaunchId): the tag base of the next one
+    // prologue staged ahead of its call (mfcd_train_call_stage): which call it belongs to and which set of regions it wrote
+    struct Staged {
+        bool valid = false;
+        const void *samples = nullptr, *U = nullptr;
+        int64_t N = 0, step0 = 0;
+        float *loss = nullptr;
+        int set = 0;
+    } staged;
+    int last_set = 0;             // set of regions the most recently enqueued persistent launch reads
+    bool lists_dirty[2] = {false, false};   // a prologue filled this set's event lists and no launch has consumed them (the
+                                  // launch zeroes the counters it read): a staged prologue whose call never came.  The
+                                  // next prologue into the set zeroes the counters first instead of appending to them
     bool terms_dirty = false;     // a call that keeps plain fp32 terms (streaming / local / generic resident) wrote the term
                                   // region: zeroed before the next launch that reads it as tagged granules
     bool mailbox_dirty = false;   // a streaming-form call wrote U_alt / V_alt over the head of the mailbox (same union):
@@ -760,7 +786,7 @@ template <typename TP>
 int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *samples,
                     int64_t N, int B, int64_t step0, int n, int m, int d, double lr, double beta1, double beta2,
                     double eps, double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
-                    void *stream, float *timing_us)
+                    void *stream, float *timing_us, bool stage_only = false)
 {
     if (int rc = check_common(U, V, n, m, d)) return rc;
     if (!mU || !vU || !mV || !vV || N < 0 || B <= 0 || step0 < 0) return MFCD_EINVAL;
@@ -780,34 +806,69 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
     const FormChoice fc = choose_form(kF32, L.resident, L.ev.tshift, N, B, n, m, d);
     if (fc.form < 0) return fc.form;
 
+    if (stage_only && !(fc.form == 2 && fc.rp.lookahead > 0 && L.two_sets)) return 0;   // nothing to stage for this form
     if (fc.form == 2 || fc.form == 3) {
         // ---- persistent forms: ONE launch for all nsteps (resident.hip / local.hip) behind ONE prologue kernel ----
         const bool resident = fc.form == 2;
         // look-ahead form (B <= 64): the batch means are formed inside the launch; otherwise by batch_mean_kernel
         const bool means_inside = resident && fc.rp.lookahead > 0;
-        StepScalars *sc_dev = (StepScalars *)(base + L.stage_off + kColdBytes);
+        // which set of prologue-written regions this call uses: the one its prologue was staged into (if this is the
+        // staged call), the other one when staging now, else the set of the last launch (free again in stream order)
+        const bool staged_hit = !stage_only && S->staged.valid && S->staged.samples == (const void *)samples &&
+                                S->staged.U == (const void *)U &&
+                                S->staged.N == N && S->staged.step0 == step0 && S->staged.loss == loss_per_step &&
+                                means_inside && !timing_us;
+        const int set = staged_hit ? S->staged.set : (stage_only ? 1 - S->last_set : S->last_set);
+        if (!stage_only && S->staged.valid && S->staged.set == set && !staged_hit) S->staged.valid = false;   // overwritten below
+        const size_t stage_off = set ? L.stage2_off : L.stage_off, evcnt_off = set ? L.evcnt2_off : L.evcnt_off;
+        const size_t event_off = set ? L.event2_off : L.event_off, xs_off = set ? L.xs2_off : L.xs_off;
+        StepScalars *sc_dev = (StepScalars *)(base + stage_off + kColdBytes);
         void *terms = base + L.terms_off;
         StageSlot *slot = nullptr;
         const size_t need = kColdBytes + sizeof(StepScalars) * (size_t)(nsteps + 1);
         // short calls: the table is built on this thread's stack and copied into the prologue's kernel arguments at launch
         alignas(16) unsigned char inline_stage[4096];
         const bool stage_inline = need <= mfcd_detail::train_inline_stage_bytes() && need <= sizeof(inline_stage);
-        if (!stage_inline)
+        if (!stage_inline && !staged_hit)
             if (int rc = stage_acquire(*S, need, &slot)) return rc;
-        void *const stage_host = stage_inline ? (void *)inline_stage : slot->host;
+        void *const stage_host = (stage_inline || staged_hit) ? (void *)inline_stage : slot->host;
         void **cold = (void **)stage_host;   // ResidentCold (resident_kernel.h)
+        if (!staged_hit) {
         cold[0] = U; cold[1] = V; cold[2] = mU; cold[3] = vU; cold[4] = mV; cold[5] = vV; cold[6] = status;
         cold[7] = (void *)(uintptr_t)mfcd_detail::g_tune.spin_limit;
-        cold[8] = base + L.evcnt_off;
-        cold[9] = base + L.event_off;
+        cold[8] = base + evcnt_off;
+        cold[9] = base + event_off;
         cold[10] = (void *)(uintptr_t)L.nch_cap;
         cold[11] = (void *)(uintptr_t)fc.rp.tshift;
         cold[12] = means_inside ? (void *)loss_per_step : nullptr;
         for (int k = 13; k < 16; ++k) cold[k] = nullptr;
         StepScalars *sc_host = (StepScalars *)((char *)stage_host + kColdBytes);
         for (int64_t k = 0; k <= nsteps; ++k) sc_host[k] = step_scalars(lr, beta1, beta2, step0 + k + 1);
+        }
 
-        mfcd_sample *xs = resident ? (mfcd_sample *)(base + L.xs_off) : nullptr;
+        mfcd_sample *xs = resident ? (mfcd_sample *)(base + xs_off) : nullptr;
+        const int rpw = resident ? 64 * fc.rp.Q / d : 0;
+        const int look = means_inside ? fc.rp.lookahead : 0;
+        if (!staged_hit && means_inside && S->lists_dirty[set]) {
+            MFCD_HIP_TRY(hipMemsetAsync(base + evcnt_off, 0, L.evcnt_bytes, st));
+            S->lists_dirty[set] = false;
+        }
+        if (stage_only) {
+            // the prologue of a LATER call, on the caller's side stream: stage table, translated samples, event lists
+            S->lists_dirty[set] = true;
+            if (int rc = mfcd_detail::launch_train_prologue(stage_host, stage_inline ? nullptr : slot->devview, base + stage_off,
+                                                            need, samples, N, B, n, m, rpw, fc.rp.tshift, look, L.nch_cap, xs,
+                                                            (unsigned *)(base + evcnt_off), base + event_off, st))
+                return rc;
+            if (slot) {
+                MFCD_HIP_TRY(hipEventRecord(slot->ev, st));
+                slot->pending = true;
+            }
+            S->staged.valid = true;
+            S->staged.samples = samples; S->staged.U = U; S->staged.N = N; S->staged.step0 = step0; S->staged.loss = loss_per_step;
+            S->staged.set = set;
+            return 0;
+        }
         unsigned long long *mailbox = (unsigned long long *)(base + L.mailbox_off);
         unsigned tag_base = 0;
         if (resident) {
@@ -831,12 +892,17 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
             }
         }
         if (!means_inside) S->terms_dirty = true;
-        const int rpw = resident ? 64 * fc.rp.Q / d : 0;
-        const int look = means_inside ? fc.rp.lookahead : 0;
-        if (int rc = mfcd_detail::launch_train_prologue(stage_host, stage_inline ? nullptr : slot->devview, base + L.stage_off, need, samples, N, B, n,
-                                                        m, rpw, fc.rp.tshift, look, L.nch_cap, xs,
-                                                        (unsigned *)(base + L.evcnt_off), base + L.event_off, st))
+        if (staged_hit) {
+            S->staged.valid = false;          // consumed: its prologue ran on the side stream (the caller ordered the streams)
+        } else if (int rc = mfcd_detail::launch_train_prologue(stage_host, stage_inline ? nullptr : slot->devview,
+                                                               base + stage_off, need, samples, N, B, n, m, rpw,
+                                                               fc.rp.tshift, look, L.nch_cap, xs,
+                                                               (unsigned *)(base + evcnt_off), base + event_off, st))
             return rc;
+        if (resident) {
+            S->last_set = set;
+            S->lists_dirty[set] = false;      // the launch below reads the lists and leaves their counters at zero
+        }
 
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing_us) {
@@ -846,7 +912,7 @@ int run_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, co
         }
         int rc = 0;
         if (resident)
-            rc = mfcd_detail::launch_resident_steps(fc.rp, base + L.stage_off, xs, N, B, n, m, d, sc_dev,
+            rc = mfcd_detail::launch_resident_steps(fc.rp, base + stage_off, xs, N, B, n, m, d, sc_dev,
                                                     adam_static(beta1, beta2, eps, weight_decay), mailbox, tag_base,
                                                     terms, (unsigned long long *)(base + L.dbg_off), (int)nsteps, st);
         else
@@ -1028,6 +1094,20 @@ extern "C" int mfcd_train_call_run(void *handle, const mfcd_sample *samples, int
     return run_train_steps<float>((float *)c->U, (float *)c->V, c->mU, c->vU, c->mV, c->vV, samples, N, c->B, step0,
                                   c->n, c->m, c->d, c->lr, c->beta1, c->beta2, c->eps, c->wd, loss_per_step,
                                   c->workspace, c->workspace_bytes, stream, nullptr);
+}
+
+extern "C" int mfcd_train_call_stage(void *handle, const mfcd_sample *samples, int64_t N, int64_t step0,
+                                     float *loss_per_step, void *side_stream)
+{
+    const TrainCall *c = (const TrainCall *)handle;
+    if (!c) return MFCD_EINVAL;
+    if (c->bf16)
+        return run_train_steps<mfcd_bf16>((mfcd_bf16 *)c->U, (mfcd_bf16 *)c->V, c->mU, c->vU, c->mV, c->vV, samples, N,
+                                          c->B, step0, c->n, c->m, c->d, c->lr, c->beta1, c->beta2, c->eps, c->wd,
+                                          loss_per_step, c->workspace, c->workspace_bytes, side_stream, nullptr, true);
+    return run_train_steps<float>((float *)c->U, (float *)c->V, c->mU, c->vU, c->mV, c->vV, samples, N, c->B, step0,
+                                  c->n, c->m, c->d, c->lr, c->beta1, c->beta2, c->eps, c->wd, loss_per_step,
+                                  c->workspace, c->workspace_bytes, side_stream, nullptr, true);
 }
 
 extern "C" int mfcd_train_call_release(void *handle)

@@ -33,6 +33,7 @@ SIGNATURES = {
                                [_vp, _vp, _sz, _vp, _vp]),
     "mfcd_train_call_prepare": (_i32, [_vp] * 6 + [_i32] * 5 + [_dbl] * 5 + [_vp, _sz, ctypes.POINTER(ctypes.c_void_p)]),
     "mfcd_train_call_run": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "mfcd_train_call_stage": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "mfcd_train_call_release": (_i32, [_vp]),
     "mfcd_batch_coefficients": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfcd_apply_step": (_i32, [_vp] * 8 + [_i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _sz, _vp]),

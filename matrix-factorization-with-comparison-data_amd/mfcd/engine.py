@@ -215,7 +215,9 @@ class SampleStore:
 class StreamPrefetch:
     """Builds an epoch's record stream (order upload + device gather) on a side stream, so that it runs UNDER the
     previous epoch's persistent step kernel instead of between two epochs (the kernel leaves wave slots free; the
-    gather is ~50 us of the ~1 ms epoch at C2).  `take()` makes the consumer stream wait for it."""
+    gather is ~25 us of the ~0.6 ms epoch at C2) — and, round 3, STAGES the next call's prologue there too
+    (include/mfcd.h: mfcd_train_call_stage: sample translation and the per-wave event lists, ~14 us at C2).
+    `take()` makes the consumer stream wait for it."""
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -225,9 +227,16 @@ class StreamPrefetch:
         self.side.wait_stream(torch.cuda.current_stream(self.device))
         self.pending = None
 
-    def start(self, store, order):
+    def start(self, store, order, after=None, stage=None):
+        """after: an event the side stream waits for first (the step-kernel launch TWO calls back: a staged prologue
+        writes the set of workspace regions that launch read); stage(rec, side_stream): stages the call that will
+        consume `rec` (stage_next_call below)."""
         with torch.cuda.stream(self.side):
+            if after is not None:
+                self.side.wait_event(after)
             rec = store.ordered(order)
+            if stage is not None:
+                stage(rec, self.side)
             ev = torch.cuda.Event()
             ev.record(self.side)
         self.pending = (rec, ev)
@@ -239,6 +248,25 @@ class StreamPrefetch:
         main.wait_event(ev)
         rec.record_stream(main)               # allocated on the side stream, consumed on the main one
         return rec
+
+
+def stage_next_call(binding, samples_dev, batch_size, loss_out, side_stream):
+    """Run the prologue of the NEXT train_steps(binding, samples_dev, batch_size, loss_out=loss_out) call now, on
+    `side_stream` (include/mfcd.h: mfcd_train_call_stage).  Ordering is the caller's (StreamPrefetch does it): the side
+    stream must already wait for every launch on this workspace OLDER than the most recent one (the staged prologue
+    writes the set of regions the most recent launch is not using), and the stream of the consuming call must wait
+    for the side stream.  A staged prologue whose call never comes costs nothing but its own time: the library clears
+    what it left before that set is written again.  Returns False when there is nothing to stage (no prepared call
+    yet, another form, another workspace plan)."""
+    fc = binding._fast
+    N = samples_dev.shape[0]
+    if fc is None or not fc.still_valid(N, batch_size) or not samples_dev.is_contiguous():
+        return False
+    code = _lib.load().mfcd_train_call_stage(fc.handle, samples_dev.data_ptr(), N, binding.step, loss_out.data_ptr(),
+                                             side_stream.cuda_stream)
+    if code:
+        _lib.check(code)
+    return True
 
 
 class Workspace:
@@ -588,20 +616,28 @@ def fit(model, train_loader, val_loader, optimizer, num_epochs, progress=None):
     it = range(num_epochs) if progress is None else progress(range(num_epochs))
     # The host draws the epoch orders in the reference's sequence (train_0, val_0, train_1, val_1, ...: every
     # iter(loader) consumes the global generator), but the NEXT epoch's stream is built on a side stream as soon as
-    # this epoch's step kernel is enqueued, i.e. underneath it.
+    # this epoch's step kernel is enqueued, i.e. underneath it — and the next call's prologue is staged there too.
     pre = StreamPrefetch(dev)
     bs = None
+    launched = []            # one event per enqueued train call: a staged prologue reuses the regions of the call two back
     try:
         if num_epochs > 0:
             order, bs = epoch_order(train_loader)           # structure.py:845 iter(train_loader)
             pre.start(train, order)
+        nsteps = n_batches(train.N, bs) if bs else 0
+        loss_bufs = torch.empty((max(num_epochs, 1), max(nsteps, 1)), dtype=torch.float32, device=dev)
         for e in it:
             stream = pre.take()
-            per_epoch_train.append(train_steps(binding, stream, bs, defer_step=True))
+            per_epoch_train.append(train_steps(binding, stream, bs, loss_out=loss_bufs[e], defer_step=True))
+            ev = torch.cuda.Event()
+            ev.record()
+            launched.append(ev)
             vorder, vbs = epoch_order(val_loader)           # structure.py:861 iter(val_loader)
             if e + 1 < num_epochs:
                 order, bs = epoch_order(train_loader)       # next epoch's structure.py:845
-                pre.start(train, order)
+                nxt = loss_bufs[e + 1]
+                pre.start(train, order, after=launched[e - 1] if e >= 1 else None,
+                          stage=lambda rec, side, nxt=nxt: stage_next_call(binding, rec, bs, nxt, side))
             vl, _, _ = eval_batches(U, V, val.ordered(vorder), vbs)
             per_epoch_val.append(vl)
     finally:

@@ -1564,3 +1564,76 @@ def test_row_block_sharded_uvt_pass_rehearsal_at_c5_shape(dev, orc):
     got = rs_s[rows].cpu().numpy()
     np.testing.assert_allclose(got[:, 1], ref_rows[:, 1], rtol=2e-5)
     np.testing.assert_allclose(got[:, 2], ref_rows[:, 2], rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_staged_prologue_gives_the_same_run(dev, monkeypatch):
+    """engine.fit stages every epoch's prologue (sample translation, per-wave event lists) on a side stream under the
+    previous epoch's step kernel (mfcd_train_call_stage, second set of prologue regions).  Same inputs to the same step
+    kernel: the run must be BIT-identical to one whose prologues all run in-stream, epoch losses included, and the
+    staged descriptor must not leak into a call on other samples."""
+    from mfcd import engine
+    n, m, d, N = 640, 512, 64, 64 * 150 + 17
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=31)
+    rows = np.stack([u, i, j, z], 1)
+    mk = lambda r, sh: torch.utils.data.DataLoader(ListDataset(r), batch_size=64, shuffle=sh)   # noqa: E731
+    engine.set_train_path("resident")
+    try:
+        outs = []
+        for staged in (True, False):
+            if not staged:
+                monkeypatch.setattr(engine, "stage_next_call", lambda *a, **k: False)
+            model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+            torch.manual_seed(7)
+            tl, vl = engine.fit(model, mk(rows, True), mk(rows[:640], False), opt, 5)
+            # a call on OTHER samples right after: must not pick up a staged prologue
+            extra = engine.train_steps(engine.AdamBinding(model, opt), _records(u[:640], i[:640], j[:640], z[:640], n, m, dev).dev, 64)
+            outs.append((tl, vl, model.U.data.clone(), model.V.data.clone(), extra.clone(),
+                         opt.state[model.U]["exp_avg_sq"].clone()))
+        engine.check_status()
+    finally:
+        engine.set_train_path("auto")
+    a, b = outs
+    assert a[0] == b[0] and a[1] == b[1]
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_abandoned_staged_prologue_leaves_no_trace(dev):
+    """A staged prologue whose call never comes (the caller went on with other samples, or with another step count)
+    leaves its set's per-wave event lists filled: the next prologue into that set must start from empty lists, not
+    append to them (train.hip: WsState::lists_dirty).  Stage A, abandon it, run B in-stream, stage C over A's set, run
+    C: BIT-identical to the same two calls with nothing staged."""
+    from mfcd import engine
+    n, m, d, N = 640, 512, 64, 64 * 150 + 17
+    U0, V0, u, i, j, z = _synthetic(n, m, d, 3 * N, seed=33)
+    recs = [_records(u[k * N:(k + 1) * N], i[k * N:(k + 1) * N], j[k * N:(k + 1) * N], z[k * N:(k + 1) * N], n, m, dev).dev
+            for k in range(3)]
+    side = torch.cuda.Stream(device=dev)
+    engine.set_train_path("resident")
+    try:
+        outs = []
+        for staged in (True, False):
+            model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+            bind = engine.AdamBinding(model, opt)
+            nb = (N + 63) // 64
+            loss = [torch.empty(nb, device=dev) for _ in range(3)]
+            engine.train_steps(bind, recs[1], 64, loss_out=loss[1])          # makes the prepared call
+            torch.cuda.synchronize()
+            if staged:
+                assert engine.stage_next_call(bind, recs[0], 64, loss[0], side)      # A: never run
+                torch.cuda.synchronize()
+            engine.train_steps(bind, recs[1], 64, loss_out=loss[1])          # B, in-stream
+            torch.cuda.synchronize()
+            if staged:
+                assert engine.stage_next_call(bind, recs[2], 64, loss[2], side)      # C over A's set
+                torch.cuda.synchronize()
+            engine.train_steps(bind, recs[2], 64, loss_out=loss[2])
+            torch.cuda.synchronize()
+            outs.append((model.U.data.clone(), model.V.data.clone(), loss[1].clone(), loss[2].clone()))
+        engine.check_status()
+    finally:
+        engine.set_train_path("auto")
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
