@@ -201,6 +201,15 @@ void resident_train_kernel(ResidentArgs a)
 #ifdef MFCD_RES_STATS
     u64 rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const u64 rs_t0 = RS_NOW();
+    // -DMFCD_RES_STAMPS (tools/diag_short_call_stamps.py): absolute times (constant 100 MHz counter) of wave start, loop
+    // start, loop end, wave end instead of slots 1, 2, 3, 7, and a second bank (dbg[8 + 4096*8 + wave*8 ..], s_memtime
+    // ticks summed over the wave's hit steps): 0 event-step start -> first granule load  1 load -> every tag right
+    // 2 -> end of the hit arithmetic  3 -> dense update done  4 -> touched rows published  5 hit steps
+    // 6 the same as 1 for hits whose first look succeeded  7 their number
+    [[maybe_unused]] const u64 rs_abs_t0 = __builtin_amdgcn_s_memrealtime();
+    [[maybe_unused]] u64 rs_abs_l0 = 0, rs_abs_l1 = 0;
+    [[maybe_unused]] u64 rs_hit[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] u64 rs_mark = 0;
 #endif
     // ---- load my slice of the state into registers ----
     float p[Q], m1[Q], m2[Q], gr[GRL ? 1 : Q];
@@ -314,6 +323,9 @@ void resident_train_kernel(ResidentArgs a)
         unsigned spins = 0, limit = 0;
         [[maybe_unused]] u64 rs_w0 = 0;
         RS_ADD(4, 1ull);
+#ifdef MFCD_RES_STAMPS
+        { const u64 t = RS_NOW(); rs_hit[0] += t - rs_mark; rs_mark = t; }
+#endif
         while (true) {
             bool ok = true;
 #pragma unroll
@@ -342,6 +354,9 @@ void resident_train_kernel(ResidentArgs a)
 #ifdef MFCD_RES_STATS
         if (spins) RS_ADD(2, RS_NOW() - rs_w0);
         else RS_ADD(4, 1ull << 40);
+#endif
+#ifdef MFCD_RES_STAMPS
+        { const u64 t = RS_NOW(); rs_hit[1] += t - rs_mark; if (!spins) { rs_hit[6] += t - rs_mark; rs_hit[7] += 1; } rs_mark = t; }
 #endif
 
         float acc = 0.0f;
@@ -405,6 +420,9 @@ void resident_train_kernel(ResidentArgs a)
                 if (own[2] && rowq == lrs[2]) gr[q] += -dv[sq];
             }
         }
+#ifdef MFCD_RES_STAMPS
+        { const u64 t = RS_NOW(); rs_hit[2] += t - rs_mark; rs_mark = t; }
+#endif
         return true;
     };
 
@@ -660,6 +678,7 @@ void resident_train_kernel(ResidentArgs a)
 #ifdef MFCD_RES_STATS
             const u64 rs_l0 = RS_NOW();
             rs_acc[6] = rs_l0 - rs_t0;
+            rs_abs_l0 = __builtin_amdgcn_s_memrealtime();
 #endif
             int k = 0;
             while (true) {
@@ -694,6 +713,9 @@ void resident_train_kernel(ResidentArgs a)
                     // it issues ahead of them until its step is done
                     __builtin_amdgcn_s_setprio(3);
                     [[maybe_unused]] const u64 rs_e0 = RS_NOW();
+#ifdef MFCD_RES_STAMPS
+                    rs_mark = rs_e0;
+#endif
                     RS_ADD(7, 1ull << 32);
                     if (k == chunk_end) {
                         load_chunk(++chunk);
@@ -738,15 +760,22 @@ void resident_train_kernel(ResidentArgs a)
                     RS_ADD(1, RS_NOW() - rs_e0);
                 }
                 step_update(hit, sc_cur);
+#ifdef MFCD_RES_STAMPS
+                if (hit) { const u64 t = RS_NOW(); rs_hit[3] += t - rs_mark; rs_mark = t; }
+#endif
                 if (__builtin_expect(hit, 0)) {
                     publish_fresh(k, hc, pc, h0, hc);              // rows batch k touched: their next use, if within W steps
                     __builtin_amdgcn_s_setprio(0);
+#ifdef MFCD_RES_STAMPS
+                    { const u64 t = RS_NOW(); rs_hit[4] += t - rs_mark; rs_hit[5] += 1; }
+#endif
                 }
                 sc_cur = sc_next;
                 ++k;
             }
             __builtin_amdgcn_s_setprio(0);
 #ifdef MFCD_RES_STATS
+            rs_abs_l1 = __builtin_amdgcn_s_memrealtime();
             rs_acc[0] = RS_NOW() - rs_l0;
             rs_acc[6] |= (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32;    // HW_ID: wave / SIMD / CU / SH / SE
             rs_acc[5] |= (u64)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;   // XCC_ID
@@ -818,6 +847,13 @@ void resident_train_kernel(ResidentArgs a)
             }
         }
     }
+#ifdef MFCD_RES_STAMPS
+    if (lane == 0 && a.dbg) {
+        u64 *const o = a.dbg + 8 + (int64_t)gw * 8;
+        o[1] = rs_abs_t0; o[2] = rs_abs_l0; o[3] = rs_abs_l1; o[7] = __builtin_amdgcn_s_memrealtime();
+        for (int x = 0; x < 8; ++x) o[4096 * 8 + x] = rs_hit[x];
+    }
+#endif
 }
 
 }  // namespace mfcd_detail

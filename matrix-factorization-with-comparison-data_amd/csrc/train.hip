@@ -451,7 +451,7 @@ int device_cus()
 }
 
 constexpr size_t kColdBytes = 128;  // ResidentCold (resident_kernel.h), directly in front of the scalar table
-constexpr size_t kDbgBytes = 256 + 16 * 256 * 8 * 8;  // [8] who gave up first + [<=4096 waves][8] u64 of the diagnostic build (tools/)
+constexpr size_t kDbgBytes = 256 + 2 * 16 * 256 * 8 * 8;  // [8] who gave up first + 2 banks of [<=4096 waves][8] u64 of the diagnostic builds (tools/)
 constexpr size_t kMaxMailboxBytes = (size_t)24 << 30;  // beyond this the resident form is not planned
 constexpr int kTagStepBits = 21;    // granule tag = launch id << 21 | (step + 1)
 constexpr unsigned kMaxLaunchId = (1u << (32 - kTagStepBits)) - 1;

@@ -492,6 +492,39 @@ def _dp_cost_model(cfg, world, sharded):
                     "GPU's registers (C4: 32 us per step on one GPU)"}
 
 
+def _bench_independent_replicas(cfg, dev, steps, warmup, seed):
+    """The form in which the reference's OWN workload uses several GPUs (Runs.ipynb: grids x repetitions through
+    parameter_scan; structure.scan_over_ranks here): every rank trains its own model on its own data with the single-GPU
+    step form, no data-path collective.  Same timing rule as the headline (barrier + synchronize on both sides, max over
+    ranks); value = samples all ranks consumed / that time."""
+    import time
+
+    import bench as bench_mod
+    world, rank = dist.get_world_size(), dist.get_rank()
+    runner = bench_mod.Runner(cfg, dev, seed + 7919 * (rank + 1))
+    runner.open_epoch()
+    runner.run(max(warmup, runner.steps_per_epoch))
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    consumed = runner.run(steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0, float(consumed)], dtype=torch.float64, device=dev)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    runner.bind.flush()
+    engine.check_status()
+    dt, total = float(tmax[0].item()), float(t[1].item())
+    return {"value": round(total / dt, 1), "unit": "triplet-updates/s", "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 6),
+            "scaling": "weak", "collectives_on_the_data_path": 0,
+            "step_form": engine.train_plan(min(steps, runner.steps_per_epoch) * cfg["B"], cfg["B"], cfg["n"], cfg["m"],
+                                           cfg["d"])["form_name"],
+            "what": "one independent training run per rank (own model, own samples, batch 64, the single-GPU step form): "
+                    "the way the reference's parameter scans spread over GPUs (structure.scan_over_ranks)"}
+
+
 def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native", extras=True):
     """bench.py's N>1 leg: weak scaling, per-rank batch cfg['B'], global batch B*world; returns the JSON dict.
     extras: also probe the per-phase split, attach the cost model and (C2 headline) a `c4` sub-record — BASELINE
@@ -628,6 +661,10 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native", extras=Tru
                     sub[form]["cost_model"] = {k: cm[k] for k in ("per_step_us", "sum_us", "predicted_value")}
                 except Exception as e:       # the headline stands on its own
                     sub[form] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            try:
+                out["independent_replicas"] = _bench_independent_replicas(cfg, dev, steps, warmup, seed)
+            except Exception as e:
+                out["independent_replicas"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             out["c4"] = {"workload": "BASELINE configs[3]: n=m=65536, d=64, p=0.0005, K=4 (3.4 M training samples), "
                                      "8-GPU data parallel", "forms": sub}
     return out

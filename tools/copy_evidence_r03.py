@@ -22,7 +22,8 @@ for name in ("bench_c2_default.json", "bench_c2_driver_cmd.json", "bench_c2_driv
              "tiny_problem_forms.txt", "resident_pmc_c2.txt", "resident_pmc_c3.txt", "streaming_pmc_C4.txt",
              "streaming_pmc_C5.txt", "resident_common_path.txt", "uvt_pass_vs_load_history.txt",
              "driver_call_event_pair_cost.txt", "valu_issue_microbench.txt", "metric_functions_c5.txt",
-             "resident_wave_accounting.txt", "uvt_pmc.txt"):
+             "resident_wave_accounting.txt", "uvt_pmc.txt", "short_call_wave_timeline.txt", "gpu_tests.log",
+             "fuzz_parity.txt", "fuzz_bf16.txt", "fuzz_multi_gpu_rehearsal.txt", "fuzz_uvt.txt"):
     if os.path.exists(os.path.join(E, name)):
         cp(os.path.join(E, name), "r03_" + name)
 subprocess.run([sys.executable, "tools/pmc_traffic.py", f"{E}/pmc_c2_fetch", f"{E}/pmc_c2_write", "profiles/r03_pmc_traffic.json"],

@@ -1,5 +1,5 @@
 # Collects round-3 measurement evidence on the MI355X box into gpurun_out/ev3/ (tools/copy_evidence_r03.py -> profiles/).
-# usage: round3_evidence.sh bench | prof | pmc      (three calls: each stays well under the 20-minute gpurun limit)
+# usage: round3_evidence.sh bench | prof | pmc | fuzz      (three calls: each stays well under the 20-minute gpurun limit)
 R=$GRAFT_REPO_ROOT
 E=$R/gpurun_out/ev3
 mkdir -p $E
@@ -20,7 +20,14 @@ timeout -k 10 300 python tools/diag_short_calls.py 20 > $E/short_call_breakdown.
 timeout -k 10 300 bash tools/exp_short_call_sweep.sh >> $E/short_call_breakdown.txt 2>&1; tail -7 $E/short_call_breakdown.txt
 timeout -k 10 300 python tools/diag_common_path.py > $E/resident_common_path.txt 2>&1; timeout -k 10 300 python tools/diag_common_path.py C3 >> $E/resident_common_path.txt 2>&1; grep "B=" $E/resident_common_path.txt
 MFCD_LIB=$R/matrix-factorization-with-comparison-data_amd/libmfcd_hip_diag.so timeout -k 10 300 python tools/diag_resident_stats.py > $E/resident_wave_accounting.txt 2>&1; head -8 $E/resident_wave_accounting.txt
+MFCD_LIB=$R/matrix-factorization-with-comparison-data_amd/libmfcd_hip_stamps.so timeout -k 10 300 python tools/diag_short_call_stamps.py 20 > $E/short_call_wave_timeline.txt 2>&1; MFCD_LIB=$R/matrix-factorization-with-comparison-data_amd/libmfcd_hip_stamps.so timeout -k 10 300 python tools/diag_short_call_stamps.py 100 >> $E/short_call_wave_timeline.txt 2>&1; python tools/sim_chain_depth.py >> $E/short_call_wave_timeline.txt 2>&1; tail -12 $E/short_call_wave_timeline.txt
 timeout -k 10 300 python tools/bench_forms_tiny.py > $E/tiny_problem_forms.txt 2>&1; tail -8 $E/tiny_problem_forms.txt
+fi
+if [ "$1" = "fuzz" ]; then
+timeout -k 10 500 python tools/fuzz_parity.py 1500 31 > $E/fuzz_parity.txt 2>&1; tail -3 $E/fuzz_parity.txt
+timeout -k 10 300 python tools/fuzz_bf16.py 600 32 > $E/fuzz_bf16.txt 2>&1; tail -3 $E/fuzz_bf16.txt
+timeout -k 10 300 python tools/fuzz_multi.py 1000 33 > $E/fuzz_multi_gpu_rehearsal.txt 2>&1; tail -3 $E/fuzz_multi_gpu_rehearsal.txt
+timeout -k 10 300 python tools/fuzz_uvt.py 800 34 > $E/fuzz_uvt.txt 2>&1; tail -3 $E/fuzz_uvt.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 P="rocprofv3 --kernel-trace --output-format csv"
