@@ -53,10 +53,15 @@ __host__ __device__ inline int slices_for(int rows) { return rows >= 128 * kSlic
 // partial[slice][k] = sum over rows of the slice of T[row][k]  (f64), grid = (kSlices, 2 tables).
 // The 256 threads form G = 256/d row groups (1 when d >= 256): thread -> (group g, column k); a group walks every
 // G-th row of the slice with four loads in flight, the groups are combined through LDS in fixed order.
+// The first kernel of every pass: it also zeroes the pass's arrival counters (cnt[0 .. ncnt)), which the tiled main
+// kernel's tail counts workgroups with (the workspace is the caller's memory: nothing in it survives between passes).
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ U, const float *__restrict__ V,
-                                                             int n, int m, int d, double *__restrict__ part)
+                                                             int n, int m, int d, double *__restrict__ part,
+                                                             unsigned *__restrict__ cnt, int ncnt)
 {
     __shared__ double red[256];
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < ncnt; i += 256) cnt[i] = 0u;
     const bool isV = blockIdx.y == 1;
     const float *T = isV ? V : U;
     const int rows = isV ? m : n;
@@ -70,17 +75,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
         const int g = d >= 256 ? 0 : (int)threadIdx.x / d;
         const int k = d >= 256 ? kb + (int)threadIdx.x : (int)threadIdx.x % d;
         const bool live = g < G && k < d;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        // sixteen loads in flight per thread (a slice is a few such batches: the kernel is a chain of memory round trips)
+        double a[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) a[x] = 0.0;
         if (live) {
             int r = r0 + g;
+            for (; r + 15 * G < r1; r += 16 * G) {
+                float t[16];
+#pragma unroll
+                for (int x = 0; x < 16; ++x) t[x] = T[(int64_t)(r + x * G) * d + k];
+#pragma unroll
+                for (int x = 0; x < 16; ++x) a[x] += (double)t[x];
+            }
             for (; r + 3 * G < r1; r += 4 * G) {
                 const float t0 = T[(int64_t)r * d + k], t1 = T[(int64_t)(r + G) * d + k];
                 const float t2 = T[(int64_t)(r + 2 * G) * d + k], t3 = T[(int64_t)(r + 3 * G) * d + k];
-                a0 += (double)t0; a1 += (double)t1; a2 += (double)t2; a3 += (double)t3;
+                a[0] += (double)t0; a[1] += (double)t1; a[2] += (double)t2; a[3] += (double)t3;
             }
-            for (; r < r1; r += G) a0 += (double)T[(int64_t)r * d + k];
+            for (; r < r1; r += G) a[0] += (double)T[(int64_t)r * d + k];
         }
-        red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+#pragma unroll
+        for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+            for (int x = 0; x < w; ++x) a[x] += a[x + w];
+        red[threadIdx.x] = a[0];
         __syncthreads();
         if (live && g == 0) {
             double acc = 0.0;
@@ -129,24 +148,38 @@ __global__ __launch_bounds__(256) void centre_vectors_kernel(const float *__rest
                                                              int rows_per_block, float *__restrict__ rm,
                                                              float *__restrict__ cm, mfcd_bf16 *__restrict__ vsplit)
 {
-    extern __shared__ __attribute__((aligned(16))) float bar[];   // [2][d]: ubar, vbar
-    for (int idx = threadIdx.x; idx < 2 * d; idx += 256) {
-        if (bar_pre) {   // large tables: colsum_final_kernel has reduced the partial sums once
-            bar[idx] = bar_pre[idx];
-            continue;
+    extern __shared__ __attribute__((aligned(16))) float bar[];   // [2][d]: ubar, vbar (+ [4][2 d] doubles behind it, small tables)
+    if (bar_pre) {   // large tables: colsum_final_kernel has reduced the partial sums once
+        for (int idx = threadIdx.x; idx < 2 * d; idx += 256) bar[idx] = bar_pre[idx];
+    } else {
+        // same order in every workgroup and as colsum_final_kernel: ((s0+s4+..) + (s1+s5+..)) + ((s2+..) + (s3+..)), the tail
+        // slices on the first.  One work item per (column, quarter): its loads are independent and issued eight at a
+        // time — the prologue of every workgroup of this kernel used to be a chain of ~nsl/4 memory round trips
+        double *quart = reinterpret_cast<double *>(bar + 2 * d + (2 * d & 1));   // [4][2 d]
+        for (int item = threadIdx.x; item < 8 * d; item += 256) {
+            const int q = item / (2 * d), idx = item - q * 2 * d;
+            const int tab = idx / d, k = idx - tab * d;
+            const int rows = tab ? m : n, nsl = slices_for(rows), full = nsl & ~3;
+            const double *src = part + (size_t)tab * kSlices * d + k;
+            double a = 0.0;
+            int sl = q;
+            for (; sl + 28 < full; sl += 32) {
+                double t[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) t[x] = src[(size_t)(sl + 4 * x) * d];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) a += t[x];
+            }
+            for (; sl < full; sl += 4) a += src[(size_t)sl * d];
+            if (q == 0)
+                for (sl = full; sl < nsl; ++sl) a += src[(size_t)sl * d];
+            quart[q * 2 * d + idx] = a;
         }
-        const int tab = idx / d, k = idx - tab * d;
-        const int rows = tab ? m : n, nsl = slices_for(rows);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // same order in every workgroup: (s0+s4+..)+(s1+..)+..
-        int sl = 0;
-        for (; sl + 3 < nsl; sl += 4) {
-            a0 += part[((size_t)tab * kSlices + sl) * d + k];
-            a1 += part[((size_t)tab * kSlices + sl + 1) * d + k];
-            a2 += part[((size_t)tab * kSlices + sl + 2) * d + k];
-            a3 += part[((size_t)tab * kSlices + sl + 3) * d + k];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 2 * d; idx += 256) {
+            const int rows = idx >= d ? m : n;
+            bar[idx] = (float)(((quart[idx] + quart[2 * d + idx]) + (quart[4 * d + idx] + quart[6 * d + idx])) / (double)rows);
         }
-        for (; sl < nsl; ++sl) a0 += part[((size_t)tab * kSlices + sl) * d + k];
-        bar[idx] = (float)(((a0 + a1) + (a2 + a3)) / (double)rows);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -445,12 +478,33 @@ __device__ __forceinline__ void split_read_batch(f32x4 (&t)[4], unsigned abase, 
 // the fragment-major layout centre_vectors_kernel writes (same bytes per row, same stage and piece arithmetic; a
 // wave's fragment read is one contiguous KiB, so the stage needs no padding), and the wave splits its own U rows once.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// What the tiled kernel's TAIL needs (round 3: the final reduction is no launch of its own).  The workgroups of a row
+// block (one per column split) count themselves in at cnt[1 + row block] once their partial sums are written; the one
+// that arrives last re-centres the block's rows in f64 (the arithmetic of the former uvt_final_tiled_kernel) and writes
+// the block's share of the two global sums; row blocks count themselves in at cnt[0], and the last one adds the shares
+// in block order.  Every sum has a fixed order, whichever workgroup happens to form it: results do not depend on timing.
+// Partial sums travel between workgroups (possibly of different XCDs, whose L2s are not coherent with each other) as
+// agent-scope stores and loads: they go to the memory side themselves, so no release / acquire FENCE is needed — a fence
+// at agent scope writes back and invalidates the XCD's whole L2 on this chip, and one per finishing workgroup threw the
+// V rows the other workgroups were reading out of it (the pass took twice as long).
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct UvtTail {
+    double *row_stats;   // [n][8] (WHAT & 1)
+    double *blk;         // [row blocks][2]
+    double *scal;        // [4] (WHAT & 2)
+    unsigned *cnt;       // [1 + row blocks], zero when the kernel starts (colsum_partial_kernel)
+    double s;
+};
+
 template <int D, int NW, int TC, bool XV, int WPE = 2, bool PFX = (D <= 128), int WHAT = 3, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE)))
 void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ X,
                       const float *__restrict__ rm, const float *__restrict__ cm, int n,
-                      int m, float s, int cols_per_split, int splits, int row_blocks, double *__restrict__ part_rows,
-                      double *__restrict__ part_err, double *__restrict__ part_xx)
+                      int m, float s, int cols_per_split, int splits, int row_blocks, double *part_rows,
+                      double *part_err, double *part_xx, UvtTail tail)
 {
     constexpr int CPR = D / 4, PIECES = TC * D / 256, PPW = PIECES / NW, CMW = (TC + 63) / 64, PF = SPLIT ? 256 : 260;
     static_assert(!SPLIT || (D % 32 == 0 && D <= 256 && PFX && XV), "split-product form: d in {32, 64, 128, 256}, prefetch form");
@@ -523,7 +577,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     }
     // The row statistics of X (mean, sum x^2, centred sum of squares) come out of THIS sweep (round 1 read X a second
     // time for them): every term is taken relative to x0 = the row's first value in this split, so that the fp32
-    // per-tile sums do not cancel, and the final kernel re-centres in f64 (uvt_final_tiled_kernel).
+    // per-tile sums do not cancel, and the tail of this kernel re-centres in f64.
     float rmv = rm[myrow], x0v = X[(int64_t)myrow * m + c_begin];
     // every load so far is consumed HERE, before the loop: left pending, the wait for it would sit in front of the
     // first MFMA of every iteration (and, with an LDS-DMA in flight, be a full vmcnt(0))
@@ -829,7 +883,7 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
         atomicAdd(&mfcd_uvt_dbg[7], (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0);
     }
 #endif
-    if (!active) return;
+    if (active) {
     // a row's columns are split over the two lane halves
     sac += __shfl_xor(sac, 32, MFCD_WAVE);
     saa += __shfl_xor(saa, 32, MFCD_WAVE);
@@ -841,19 +895,130 @@ void uvt_tiled_kernel(const float *__restrict__ U, const float *__restrict__ V, 
     for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off, MFCD_WAVE);
     if ((WHAT & 1) != 0 && half == 0 && rowok) {   // kTiledRowSums doubles per (split, row): sum a c', sum a a, sum a, sum c', sum c'c', x0
         double *o = part_rows + ((size_t)split * n + row0 + l31) * kTiledRowSums;
-        o[0] = sac;
-        o[1] = saa;
-        o[2] = ssa;
-        o[3] = ssc;
-        o[4] = sscc;
-        o[5] = (double)x0v;
+        st_agent(o + 0, sac);
+        st_agent(o + 1, saa);
+        st_agent(o + 2, ssa);
+        st_agent(o + 3, ssc);
+        st_agent(o + 4, sscc);
+        st_agent(o + 5, (double)x0v);
     }
-    if ((WHAT & 2) != 0 && lane == 0) part_err[(size_t)split * ((n + 31) / 32) + rt] = err2;
+    if ((WHAT & 2) != 0 && lane == 0) st_agent(part_err + (size_t)split * ((n + 31) / 32) + rt, err2);
     if constexpr (WHAT == 2) {   // error-only pass: sum x^2 of the wave's rows (the other forms get it from the row sums)
         if (!rowok) sscc = 0.0;       // (the two lane halves of a row were combined above)
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) sscc += __shfl_xor(sscc, off, MFCD_WAVE);
-        if (lane == 0) part_xx[(size_t)split * ((n + 31) / 32) + rt] = sscc;
+        if (lane == 0) st_agent(part_xx + (size_t)split * ((n + 31) / 32) + rt, sscc);
+    }
+    }
+
+    // ---------------- tail: the last workgroup of a row block finishes its rows (see UvtTail) ----------------
+    // The tiled kernel's per-(split, row) sums are relative to the split's shift x0 (and to nothing for U V^T): they are
+    // re-centred in f64.  Per split s with n_s columns and c' = x - x0_s:  sum x = S_c' + n_s x0;
+    // sum x^2 = S_c'c' + 2 x0 S_c' + n_s x0^2;  with the fp32-rounded row mean xm the reference centres with
+    // (structure.py:987) and t = xm - x0_s:  sum (x - xm)^2 = S_c'c' - 2 t S_c' + n_s t^2,  sum a (x - xm) = S_ac' - t S_a
+    if (tail.cnt == nullptr) return;       // large pass: uvt_final_tiled_kernel finishes (whole workgroup, wave-uniform)
+    __shared__ int tail_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial sums have reached the memory side ...
+    __syncthreads();                                   // ... and every wave's, before the workgroup counts itself in
+    if (tid == 0)
+        tail_last = __hip_atomic_fetch_add(&tail.cnt[1 + rb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                            (unsigned)(splits - 1) ? 1 : 0;
+    __syncthreads();
+    if (!tail_last) return;
+    double *const tred = reinterpret_cast<double *>(&vts[0][0]);   // [2][NW * 64]; the stages are done with (barriers above)
+    const int rtiles = (n + 31) / 32;
+    double q = 0.0, e = 0.0;
+    if constexpr ((WHAT & 1) != 0) {
+        const int r = rb * NW * 32 + tid;
+        if (tid < NW * 32 && r < n) {
+            // ONE pass over the splits (independent loads): the sums above are polynomials in mu, so their coefficients
+            // are accumulated first and mu (which needs sum x) is applied at the end, all in f64
+            double sx = 0.0, s_ac = 0.0, s_a = 0.0, s_ax0 = 0.0, aa = 0.0, s_cc = 0.0, s_c = 0.0, s_cx0 = 0.0, s_n = 0.0,
+                   s_nx0 = 0.0, s_nx00 = 0.0;
+            for (int sp0 = 0; sp0 < splits; sp0 += 8) {    // eight splits' sums requested together, added in split order
+                double tv[8][kTiledRowSums];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const double *t = part_rows + ((size_t)min(sp0 + x, splits - 1) * n + r) * kTiledRowSums;
+#pragma unroll
+                    for (int y = 0; y < kTiledRowSums; ++y) tv[x][y] = ld_agent(t + y);
+                }
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const int sp = sp0 + x;
+                    if (sp < splits) {
+                        const int c0 = sp * cols_per_split;
+                        const double ns = (double)(min(m, c0 + cols_per_split) - c0);
+                        const double t0 = tv[x][0], t1 = tv[x][1], t2 = tv[x][2], t3 = tv[x][3], t4 = tv[x][4], x0 = tv[x][5];
+                        sx += t3 + ns * x0;
+                        s_ac += t0; s_a += t2; s_ax0 += x0 * t2;
+                        aa += t1;
+                        s_cc += t4; s_c += t3; s_cx0 += x0 * t3;
+                        s_n += ns; s_nx0 += ns * x0; s_nx00 += ns * x0 * x0;
+                    }
+                }
+            }
+            const float xmean = (float)(sx / (double)m);
+            const double mu = (double)xmean;
+            const double ac = s_ac - mu * s_a + s_ax0;                                           // sum a (x - mu)
+            const double cc = s_cc - 2.0 * (mu * s_c - s_cx0) + (mu * mu * s_n - 2.0 * mu * s_nx0 + s_nx00);   // sum (x - mu)^2
+            const double qr = s_cc + 2.0 * s_cx0 + s_nx00;                                       // sum x^2
+            double *o = tail.row_stats + (size_t)r * 8;
+            o[0] = ac; o[1] = aa; o[2] = fmax(0.0, cc); o[3] = (double)rm[r]; o[4] = mu;
+            o[5] = qr; o[6] = 0.0; o[7] = 0.0;
+            q = qr;
+        }
+    }
+    if constexpr ((WHAT & 2) != 0) {
+        // the block's share of the two global sums: its waves' error sums (and, error-only pass, their sum x^2), split-major
+        for (int k = tid; k < splits * NW; k += NW * 64) {
+            const int sp = k / NW, t = rb * NW + k % NW;
+            if (t < rtiles) {
+                e += ld_agent(part_err + (size_t)sp * rtiles + t);
+                if constexpr (WHAT == 2) q += ld_agent(part_xx + (size_t)sp * rtiles + t);
+            }
+        }
+        tred[tid] = e;
+        tred[NW * 64 + tid] = q;
+        __syncthreads();
+        for (int w = NW * 32; w > 0; w >>= 1) {
+            if (tid < w) {
+                tred[tid] += tred[tid + w];
+                tred[NW * 64 + tid] += tred[NW * 64 + tid + w];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            st_agent(tail.blk + 2 * rb + 0, tred[0]);
+            st_agent(tail.blk + 2 * rb + 1, tred[NW * 64]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tail_last = __hip_atomic_fetch_add(&tail.cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                                (unsigned)(row_blocks - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!tail_last) return;
+        e = q = 0.0;
+        for (int k = tid; k < row_blocks; k += NW * 64) {
+            e += ld_agent(tail.blk + 2 * k + 0);
+            q += ld_agent(tail.blk + 2 * k + 1);
+        }
+        __syncthreads();
+        tred[tid] = e;
+        tred[NW * 64 + tid] = q;
+        __syncthreads();
+        for (int w = NW * 32; w > 0; w >>= 1) {
+            if (tid < w) {
+                tred[tid] += tred[tid + w];
+                tred[NW * 64 + tid] += tred[NW * 64 + tid + w];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            tail.scal[0] = tred[0];
+            tail.scal[1] = tail.s * tail.s * tred[NW * 64];   // ||sX||_F^2  (structure.py:946)
+            tail.scal[2] = 0.0;
+            tail.scal[3] = 0.0;
+        }
     }
 }
 
@@ -901,7 +1066,7 @@ __global__ __launch_bounds__(256) void uvt_final_kernel(const double *__restrict
 }
 
 // The tiled kernel's per-(split, row) sums are relative to the split's shift x0 (and to nothing for U V^T): this
-// kernel re-centres them in f64 and writes the same row_stats / block shares as uvt_final_kernel.  Per split s with
+// kernel (LARGE passes; short ones finish in the tiled kernel's tail, same arithmetic) re-centres them in f64 and writes the same row_stats / block shares as uvt_final_kernel.  Per split s with
 // n_s columns and c' = x - x0_s:  sum x = S_c' + n_s x0;  sum x^2 = S_c'c' + 2 x0 S_c' + n_s x0^2;  with the fp32-rounded
 // row mean xm the reference centres with (structure.py:987) and t = xm - x0_s:
 //   sum (x - xm)^2 = S_c'c' - 2 t S_c' + n_s t^2        sum a (x - xm) = S_ac' - t S_a
@@ -1027,6 +1192,8 @@ struct UvtWs {
     float *bar;       // [2][d]
     float *rm, *cm, *xm;
     double *scc, *sxx, *part_rows, *part_err, *part_xx, *blk, *dummy_rows, *dummy_scal;
+    unsigned *cnt;    // [1 + row tiles] arrival counters of the tiled kernel's tail (zeroed by the pass's first kernel)
+    int ncnt;
     int splits, cols_per_split, n_err, nblk;
     bool tiled;
     size_t bytes;
@@ -1106,7 +1273,9 @@ UvtWs plan_ws(char *base, int n, int m, int d)
     w.part_rows = (double *)take(sizeof(double) * (w.tiled ? kTiledRowSums : 2) * (size_t)n * w.splits);
     w.part_err = (double *)take(sizeof(double) * (size_t)w.n_err);
     w.part_xx = (double *)take(sizeof(double) * (size_t)w.n_err);
-    w.blk = (double *)take(sizeof(double) * 2 * (size_t)w.nblk);
+    w.blk = (double *)take(sizeof(double) * 2 * (size_t)(w.nblk > rtiles ? w.nblk : rtiles));
+    w.ncnt = 1 + rtiles;
+    w.cnt = (unsigned *)take(sizeof(unsigned) * (size_t)w.ncnt);
     w.dummy_rows = (double *)take(sizeof(double) * 8 * (size_t)n);   // output the caller did not ask for (select entry)
     w.dummy_scal = (double *)take(sizeof(double) * 4);
     // split-product form (d in {32, 64, 128, 256}): 4 d bytes per V row like the fp32 table, rows padded to whole stages plus one
@@ -1125,7 +1294,7 @@ int g_uvt_wpe128 = 2;   // mfcd_set_tuning(MFCD_TUNE_UVT_WPE128): 2 = X prefetch
 
 template <int DD, int NW, int TC, int WPE, bool PFX, int WHAT>
 void launch_tiled_what(const UvtWs &w, const float *U, const float *V, const float *X, int n, int m, float s, bool xv,
-                       hipStream_t st)
+                       const UvtTail &tail, hipStream_t st)
 {
     const int row_blocks = (n + NW * 32 - 1) / (NW * 32);
     const unsigned blocks = (unsigned)row_blocks * (w.splits >= 8 ? 8u * ((w.splits + 7) / 8) : (unsigned)w.splits);
@@ -1133,27 +1302,27 @@ void launch_tiled_what(const UvtWs &w, const float *U, const float *V, const flo
         if (xv && w.vsplit) {   // bf16x3 split product: V comes from the split table centre_vectors_kernel wrote
             hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, 2, true, WHAT, true>), dim3(blocks), dim3(NW * 64), 0, st, U,
                                (const float *)w.vsplit, X, w.rm, w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks,
-                               w.part_rows, w.part_err, w.part_xx);
+                               w.part_rows, w.part_err, w.part_xx, tail);
             return;
         }
     }
     if (xv)
         hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, true, WPE, PFX, WHAT>), dim3(blocks), dim3(NW * 64), 0, st, U, V,
                            X, w.rm, w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err,
-                           w.part_xx);
+                           w.part_xx, tail);
     else
         hipLaunchKernelGGL((uvt_tiled_kernel<DD, NW, TC, false, WPE, false, WHAT>), dim3(blocks), dim3(NW * 64), 0, st, U,
                            V, X, w.rm, w.cm, n, m, s, w.cols_per_split, w.splits, row_blocks, w.part_rows, w.part_err,
-                           w.part_xx);
+                           w.part_xx, tail);
 }
 
 template <int DD, int NW, int TC, int WPE = 2, bool PFX = (DD <= 128)>
 int launch_tiled(const UvtWs &w, const float *U, const float *V, const float *X, int n, int m, float s, bool xv,
-                 int what, hipStream_t st)
+                 int what, const UvtTail &tail, hipStream_t st)
 {
-    if (what == 1) launch_tiled_what<DD, NW, TC, WPE, PFX, 1>(w, U, V, X, n, m, s, xv, st);
-    else if (what == 2) launch_tiled_what<DD, NW, TC, WPE, PFX, 2>(w, U, V, X, n, m, s, xv, st);
-    else launch_tiled_what<DD, NW, TC, WPE, PFX, 3>(w, U, V, X, n, m, s, xv, st);
+    if (what == 1) launch_tiled_what<DD, NW, TC, WPE, PFX, 1>(w, U, V, X, n, m, s, xv, tail, st);
+    else if (what == 2) launch_tiled_what<DD, NW, TC, WPE, PFX, 2>(w, U, V, X, n, m, s, xv, tail, st);
+    else launch_tiled_what<DD, NW, TC, WPE, PFX, 3>(w, U, V, X, n, m, s, xv, tail, st);
     return 0;
 }
 
@@ -1211,11 +1380,11 @@ int run_uvt(const float *U, const float *V, const float *Xs, int n, int m, int d
 {
     const bool xv = (reinterpret_cast<uintptr_t>(Xs) & 15u) == 0 && m % 4 == 0;
     const bool al16 = ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15u) == 0;
-    // fused form: X read ONCE, 4-5 launches (round 1: 8 launches, X read twice); tables off a 16-byte boundary take the
+    // fused form: X read ONCE, 3 launches (round 1: 8 launches, X read twice; round 2: 4-5); tables off a 16-byte boundary take the
     // generic form (the plan's column split suits both)
     const bool tiled = ws.tiled && al16;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(slices_for(n > m ? n : m), 2), dim3(256), 0, st, U, V, n, m, d,
-                       wf.colpart);
+                       wf.colpart, ws.cnt, ws.ncnt);
     {   // 16 rows per workgroup (4 per wave).  Small tables: every workgroup reduces the few partial sums itself
         // (one launch less); large ones: one small kernel reduces them once.
         const int64_t rows = (int64_t)n + m;
@@ -1224,7 +1393,7 @@ int run_uvt(const float *U, const float *V, const float *Xs, int n, int m, int d
             hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64, 2), dim3(256), 0, st, wf.colpart, n, m, d, wf.bar);
         const int rpb = 16;
         hipLaunchKernelGGL(centre_vectors_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
-                           sizeof(float) * 2 * (size_t)d, st, U, V, wf.colpart, merged ? (const float *)nullptr : wf.bar, n,
+                           sizeof(float) * 2 * (size_t)(d + 1) + (merged ? sizeof(double) * 8 * (size_t)d : 0), st, U, V, wf.colpart, merged ? (const float *)nullptr : wf.bar, n,
                            m, d, rpb, wf.rm, wf.cm, (ws.tiled && al16 && xv && !(d == 128 && g_uvt_wpe128 == 3)) ? wf.vsplit : nullptr);
     }
     const float *Us = U + (int64_t)row0 * d;
@@ -1234,11 +1403,23 @@ int run_uvt(const float *U, const float *V, const float *Xs, int n, int m, int d
     w.vsplit = (ws.tiled && al16 && xv && !(d == 128 && g_uvt_wpe128 == 3)) ? wf.vsplit : nullptr;
     const int nn = nrows;
     if (tiled) {
-        if (d == 256) { const int rc = launch_tiled<256, 4, 32>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
-        else if (d == 128 && g_uvt_wpe128 == 3) { const int rc = launch_tiled<128, 4, 32, 3, false>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
-        else if (d == 128) { const int rc = launch_tiled<128, 4, 64, 2, true>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
-        else if (d == 64) { const int rc = launch_tiled<64, 4, 64>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
-        else { const int rc = launch_tiled<32, 4, 128>(w, Us, V, Xs, nn, m, (float)s, xv, what, st); if (rc) return rc; }
+        // short passes (C2: 37 us), three launches: column sums, centring vectors (+ split table), main kernel — whose
+        // tail finishes the rows and the two global sums (round 2: two more launches for those).  Long passes keep the
+        // separate final kernel(s): counting every workgroup in (a wait for its stores and an atomic's round trip, ~3 us
+        // of a workgroup's ~150) and the finishing workgroups at the very end cost C3 2.5 % and C5 4 %.
+        const bool fold = (int64_t)nn * m <= ((int64_t)1 << 26);
+        const UvtTail tail{row_stats, w.blk, scal, fold ? w.cnt : nullptr, s};
+        int rc = 0;
+        if (d == 256) rc = launch_tiled<256, 4, 32>(w, Us, V, Xs, nn, m, (float)s, xv, what, tail, st);
+        else if (d == 128 && g_uvt_wpe128 == 3) rc = launch_tiled<128, 4, 32, 3, false>(w, Us, V, Xs, nn, m, (float)s, xv, what, tail, st);
+        else if (d == 128) rc = launch_tiled<128, 4, 64, 2, true>(w, Us, V, Xs, nn, m, (float)s, xv, what, tail, st);
+        else if (d == 64) rc = launch_tiled<64, 4, 64>(w, Us, V, Xs, nn, m, (float)s, xv, what, tail, st);
+        else rc = launch_tiled<32, 4, 128>(w, Us, V, Xs, nn, m, (float)s, xv, what, tail, st);
+        if (rc) return rc;
+        if (fold) {
+            MFCD_HIP_TRY(hipGetLastError());
+            return 0;
+        }
         // tiny n (one row per thread), or only the global sums wanted and few enough shares: one workgroup finishes the
         // rows AND the two global sums (no uvt_scal_kernel launch)
         if (nn <= 1024 || (what == 2 && w.n_err <= 16384)) {
