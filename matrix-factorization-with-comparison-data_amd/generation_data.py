@@ -82,8 +82,7 @@ def choose_items_random(X, num_triplets, exclude):
     return list(found)
 
 
-def choose_items_by_proximity(X, num_triplets, exclude, k=100):
-    """"Min-Max": i among the user's k best items, j among the k worst (ref:29-43)."""
+def _choose_items_by_proximity_serial(X, num_triplets, exclude, k=100):
     n, m = X.shape
     kk = min(k, m)
     found, cache = set(), {}
@@ -93,10 +92,120 @@ def choose_items_by_proximity(X, num_triplets, exclude, k=100):
             row = X[u]
             cache[u] = (torch.topk(row, k=kk)[1].tolist(), torch.topk(-row, k=kk)[1].tolist())
         best, worst = cache[u]
-        i, j = np.random.choice(best), np.random.choice(worst)
+        i, j = int(np.random.choice(best)), int(np.random.choice(worst))
         if _accept((u, i, j), i, j, exclude, found):
             found.add((u, i, j))
     return list(found)
+
+
+def _legacy_choice_block(k, nwords):
+    """What the next calls of the legacy `np.random.choice(a_list_of_length_k)` return, in bulk.
+
+    numpy's RandomState.choice without p draws `randint(0, k)`, which for k - 1 < 2^32 takes one 32-bit
+    Mersenne-Twister word at a time, masks it with the smallest all-ones mask >= k - 1 and rejects values above k - 1
+    (distributions.c, buffered_bounded_masked_uint32): the sequence of returned indices is the masked word stream with
+    the rejected words dropped, whoever asks.  Draws `nwords` raw words from the global numpy generator and returns
+    (indices, pos): the indices the successive choice() calls would return and, for each, the position of its word in
+    the block (pos[t] + 1 words are consumed once t + 1 calls have returned).  Needs k >= 2 (k = 1 consumes nothing)."""
+    raw = np.random.randint(0, 2 ** 32, size=nwords, dtype=np.uint32)
+    top = k - 1
+    mask = top
+    for sh in (1, 2, 4, 8, 16):
+        mask |= mask >> sh
+    val = raw & np.uint32(mask)
+    pos = np.flatnonzero(val <= top)
+    return val[pos].astype(np.int64), pos
+
+
+def _advance_generators(t_state, n_state, torch_words, n, numpy_words):
+    """Put torch's CPU generator `torch_words` draws of randint(0, n) and numpy's global generator `numpy_words` 32-bit
+    words past the given states: where a one-attempt-at-a-time loop that used that many would have left them."""
+    torch.set_rng_state(t_state)
+    np.random.set_state(n_state)
+    if torch_words:
+        torch.randint(0, n, (torch_words,))
+    if numpy_words:
+        np.random.randint(0, 2 ** 32, size=numpy_words, dtype=np.uint32)
+
+
+def _user_item_tables(X, users, kk, worst):
+    """Rows of torch.topk indices (the reference's per-user lists) for the distinct users of a block."""
+    uu, inv = np.unique(users, return_inverse=True)
+    rows = X[torch.from_numpy(uu).to(X.device)]
+    best = torch.topk(rows, k=kk, dim=1)[1].cpu().numpy()
+    low = torch.topk(-rows, k=kk, dim=1)[1].cpu().numpy() if worst else None
+    return inv, best, low
+
+
+def _first_new(key, ok, barred, found_keys):
+    """Indices (ascending) of the attempts that add a triplet: allowed, not barred, first occurrence of their key."""
+    if barred is not None:
+        ok = ok & ~np.isin(key, barred)
+    if found_keys.size:
+        ok = ok & ~np.isin(key, found_keys)
+    idx = np.flatnonzero(ok)
+    _, first = np.unique(key[idx], return_index=True)
+    first.sort()
+    return idx[first]
+
+
+def _barred_keys(exclude, m):
+    if not exclude:
+        return None
+    return np.sort(np.fromiter(((u * m + i) * m + j for u, i, j in exclude), dtype=np.int64, count=len(exclude)))
+
+
+def _as_tuple_list(rows):
+    """list(set) of the rows inserted in attempt order: the order the reference's `list(triplets)` has."""
+    got = np.concatenate(rows) if rows else np.empty((0, 3), dtype=np.int64)
+    found = set()
+    for t in zip(got[:, 0].tolist(), got[:, 1].tolist(), got[:, 2].tolist()):
+        found.add(t)
+    return list(found)
+
+
+def choose_items_by_proximity(X, num_triplets, exclude, k=100):
+    """"Min-Max": i among the user's k best items, j among the k worst (ref:29-43): per attempt one torch.randint(n),
+    two torch.topk over the user's row and two legacy `np.random.choice(list)` calls.
+
+    Consumed in bulk without changing a draw (as `choose_items_random` does for its strategy): the users of a block of
+    attempts are one randint call, their top / bottom lists one batched topk over the distinct users, and the two
+    choices of attempt a are entries 2a and 2a + 1 of the masked-rejection stream of `_legacy_choice_block` (both
+    lists have k entries, so the two calls share range and mask).  Both generators are left where the
+    one-at-a-time loop would leave them.  The reference recomputes both topk for every attempt (O(m) each)."""
+    n, m = X.shape
+    kk = min(k, m)
+    exclude = exclude or set()
+    if kk < 2 or n >= 2 ** 32 or num_triplets <= 0 or not torch.is_tensor(X):
+        return _choose_items_by_proximity_serial(X, num_triplets, exclude, k)
+    barred = _barred_keys(exclude, m)
+    t_state, n_state = torch.get_rng_state(), np.random.get_state()
+    rows, found_keys = [], np.empty(0, dtype=np.int64)
+    attempts = words = 0
+    need = int(num_triplets)
+    span = 1 << (kk - 1).bit_length()                                            # words per accepted draw ~ span / kk
+    while need > 0:
+        A = max(4096, need + need // 4 + 64)
+        idx_stream, pos = _legacy_choice_block(kk, int(2 * A * span / kk * 1.05) + 256)
+        A = min(A, idx_stream.size // 2)
+        us = torch.randint(0, n, (A,)).numpy()
+        inv, best, low = _user_item_tables(X, us, kk, worst=True)
+        ii = best[inv, idx_stream[0:2 * A:2]].astype(np.int64)
+        jj = low[inv, idx_stream[1:2 * A:2]].astype(np.int64)
+        key = (us.astype(np.int64) * m + ii) * m + jj
+        idx = _first_new(key, ii != jj, barred, found_keys)
+        if idx.size >= need:
+            idx = idx[:need]
+            used = int(idx[-1]) + 1
+        else:
+            used = A
+        attempts += used
+        words += int(pos[2 * used - 1]) + 1
+        rows.append(np.stack((us[idx], ii[idx], jj[idx]), axis=1))
+        found_keys = np.concatenate((found_keys, key[idx]))
+        need -= idx.size
+        _advance_generators(t_state, n_state, attempts, n, words)
+    return _as_tuple_list(rows)
 
 
 def _x_pair_diff(X, us, ii, jj):
@@ -317,10 +426,13 @@ def choose_items_by_popularity(X, num_triplets, exclude, method="zipf", alpha=1.
 
 
 def choose_items_by_svd_projection(X, num_triplets, exclude, rank=10, top_fraction=0.3):
-    """Users/items with the largest truncated-SVD projection norms (ref:131-179).  As there, `rank`
-    is overridden from the sampling density and at most 5*num_triplets attempts are made."""
+    """Users/items with the largest truncated-SVD projection norms (ref:131-179).  As there, `rank` is overridden
+    from the sampling density and at most 5*num_triplets attempts are made: u uniform over the top users, (i, j) an
+    ordered pair of distinct top items.  The attempts come from an UNSEEDED numpy Generator in the reference (no draw
+    order to keep), so they are drawn and filtered in one numpy pass each block instead of one Python iteration each."""
     import scipy.sparse.linalg as spla
     n, m = X.shape
+    exclude = exclude or set()
     rank = int(num_triplets / (n * m) * max(n, m))
     Us, S, Vt = spla.svds(X.cpu().numpy(), k=rank)
     u_norm = np.linalg.norm(Us * S, axis=1)
@@ -328,25 +440,33 @@ def choose_items_by_svd_projection(X, num_triplets, exclude, rank=10, top_fracti
     top_users = np.argsort(u_norm)[-max(1, int(top_fraction * n)):]
     top_items = np.argsort(i_norm)[-max(2, int(top_fraction * m)):]
     rng = np.random.default_rng()
-    found = set()
-    for _ in range(num_triplets * 5):
-        u = int(rng.choice(top_users))
-        i, j = rng.choice(top_items, size=2, replace=False)
-        if _accept((u, i, j), i, j, exclude, found):
-            found.add((u, i, j))
-        if len(found) >= num_triplets:
-            break
+    barred = _barred_keys(exclude, m)
+    rows, found_keys = [], np.empty(0, dtype=np.int64)
+    need, budget = int(num_triplets), 5 * int(num_triplets)
+    while need > 0 and budget > 0:
+        A = min(budget, max(4096, need + need // 4 + 64))
+        us = top_users[rng.integers(0, top_users.size, size=A)].astype(np.int64)
+        a = rng.integers(0, top_items.size, size=A)
+        b = rng.integers(0, top_items.size - 1, size=A)
+        b += b >= a                                                              # uniform over the ordered distinct pairs
+        ii, jj = top_items[a].astype(np.int64), top_items[b].astype(np.int64)
+        key = (us * m + ii) * m + jj
+        idx = _first_new(key, ii != jj, barred, found_keys)[:need]
+        budget -= A
+        rows.append(np.stack((us[idx], ii[idx], jj[idx]), axis=1))
+        found_keys = np.concatenate((found_keys, key[idx]))
+        need -= idx.size
+    found = _as_tuple_list(rows)
     if len(found) < num_triplets:
         print(f"⚠️ Only {len(found)} triplets generated (target={num_triplets})")
-    return list(found)
+    return found
 
 
 def estimate_k(num_triplets):
     return math.ceil((1 + math.sqrt(1 + 8 * num_triplets)) / 2)
 
 
-def choose_items_top_k(X, num_triplets, exclude, k=None):
-    """"top_10%": both items among the user's k best, k = 10 % of the catalogue, >= 5 (ref:189-224)."""
+def _choose_items_top_k_serial(X, num_triplets, exclude, k=None):
     n, m = X.shape
     if k is None:
         k = min(m, max(5, int(0.1 * m)))
@@ -356,10 +476,10 @@ def choose_items_top_k(X, num_triplets, exclude, k=None):
         if u not in cache:
             cache[u] = torch.topk(X[u], k=k).indices.tolist()
         best = cache[u]
-        i = np.random.choice(best)
-        j = np.random.choice(best)
+        i = int(np.random.choice(best))
+        j = int(np.random.choice(best))
         while i == j:
-            j = np.random.choice(best)
+            j = int(np.random.choice(best))
         t = (u, i, j)
         if t not in found and t not in exclude:
             found.add(t)
@@ -368,6 +488,65 @@ def choose_items_top_k(X, num_triplets, exclude, k=None):
     if len(found) < num_triplets:
         print(f"⚠️ Only {len(found)} triplets generated (target={num_triplets}, k={k})")
     return list(found)
+
+
+def choose_items_top_k(X, num_triplets, exclude, k=None):
+    """"top_10%": both items among the user's k best, k = 10 % of the catalogue, >= 5 (ref:189-224); at most
+    3 * num_triplets attempts, j redrawn while it equals i.
+
+    Same draws in bulk (see `choose_items_by_proximity`): every choice has range k, so the attempts walk one
+    masked-rejection stream — attempt a takes the next index for i, then indices until one differs from it for j
+    (a cheap integer pass); the users are one randint call, their lists one batched topk."""
+    n, m = X.shape
+    exclude = exclude or set()
+    if k is None:
+        k = min(m, max(5, int(0.1 * m)))
+    if k < 2 or n >= 2 ** 32 or num_triplets <= 0 or not torch.is_tensor(X):
+        return _choose_items_top_k_serial(X, num_triplets, exclude, k)
+    barred = _barred_keys(exclude, m)
+    t_state, n_state = torch.get_rng_state(), np.random.get_state()
+    rows, found_keys = [], np.empty(0, dtype=np.int64)
+    attempts = words = 0
+    need, budget = int(num_triplets), 3 * int(num_triplets)
+    span = 1 << (k - 1).bit_length()
+    while need > 0 and attempts < budget:
+        A = min(budget - attempts, max(4096, need + need // 4 + 64))
+        idx_stream, pos = _legacy_choice_block(k, int(2 * A * (1 + 2.0 / k) * span / k * 1.05) + 256)
+        stream = idx_stream.tolist()
+        i_at, j_at = [], []
+        p, last = 0, len(stream) - 1
+        while len(i_at) < A and p < last:                                         # the reference's while i == j loop
+            q = p + 1
+            while q <= last and stream[q] == stream[p]:
+                q += 1
+            if q > last:
+                break
+            i_at.append(p)
+            j_at.append(q)
+            p = q + 1
+        A = len(i_at)
+        i_at, j_at = np.asarray(i_at, dtype=np.int64), np.asarray(j_at, dtype=np.int64)
+        us = torch.randint(0, n, (A,)).numpy()
+        inv, best, _ = _user_item_tables(X, us, k, worst=False)
+        ii = best[inv, idx_stream[i_at]].astype(np.int64)
+        jj = best[inv, idx_stream[j_at]].astype(np.int64)
+        key = (us.astype(np.int64) * m + ii) * m + jj
+        idx = _first_new(key, np.ones(A, dtype=bool), barred, found_keys)
+        if idx.size >= need:
+            idx = idx[:need]
+            used = int(idx[-1]) + 1
+        else:
+            used = A
+        attempts += used
+        words += int(pos[j_at[used - 1]]) + 1
+        rows.append(np.stack((us[idx], ii[idx], jj[idx]), axis=1))
+        found_keys = np.concatenate((found_keys, key[idx]))
+        need -= idx.size
+        _advance_generators(t_state, n_state, attempts, n, words)
+    found = _as_tuple_list(rows)
+    if len(found) < num_triplets:
+        print(f"⚠️ Only {len(found)} triplets generated (target={num_triplets}, k={k})")
+    return found
 
 
 def choose_items_cluster_based(X, num_triplets, exclude, n_clusters=20):

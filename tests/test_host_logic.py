@@ -240,6 +240,92 @@ def test_vectorised_random_sampler_equals_one_at_a_time_loop(n, m, k, n_excl):
     assert torch.equal(torch.get_rng_state(), state_want)
 
 
+def _sampler_call(G, strategy, X, want, excl, k, method, alpha):
+    if strategy == "random":
+        return G.choose_items_random(X, want, excl)
+    if strategy == "proximity":
+        return G.choose_items_by_proximity(X, want, excl, **({"k": k} if k > 0 else {}))
+    if strategy == "popularity":
+        return G.choose_items_by_popularity(X, want, excl, method=method, alpha=alpha)
+    return G.choose_items_top_k(X, want, excl, **({"k": k} if k > 0 else {}))
+
+
+def _golden_sampler_cases():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "samplers.npz"))
+    return z, [str(x) for x in z["names"]]
+
+
+@pytest.mark.parametrize("name", _golden_sampler_cases()[1])
+def test_seeded_samplers_reproduce_the_reference_lists(name):
+    """tests/golden/samplers.npz holds what the UNMODIFIED reference loops returned (oracle/make_golden_samplers.py:
+    generation_data.py:16-26, 29-43, 103-128, 189-224): the bulk forms return the same triplets in the same list order
+    and leave torch's and numpy's global generators in the same state (probed with one draw each)."""
+    import generation_data as G
+    z, _ = _golden_sampler_cases()
+    n, m, want, seed, k = (int(v) for v in z[f"{name}.meta"])
+    X = torch.from_numpy(z[f"{name}.X"])
+    excl = set(map(tuple, z[f"{name}.exclude"].tolist()))
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    got = _sampler_call(G, str(z[f"{name}.strategy"]), X, want, excl, k, str(z[f"{name}.method"]),
+                        float(z[f"{name}.alpha"][0]))
+    assert [list(t) for t in got] == z[f"{name}.triplets"].tolist()
+    after = [float(torch.rand(1, dtype=torch.float64)), float(np.random.random_sample())]
+    assert after == z[f"{name}.after"].tolist()
+
+
+@pytest.mark.parametrize("strategy,n,m,want,n_excl,k", [
+    ("proximity", 64, 150, 900, 100, 100), ("proximity", 300, 40, 2500, 0, 7), ("proximity", 9, 7, 40, 10, 3),
+    ("top_k", 64, 150, 900, 100, None), ("top_k", 5, 6, 400, 0, None), ("top_k", 300, 64, 5000, 300, None),
+    ("popularity", 50, 200, 3000, 200, None), ("popularity", 8, 5, 100, 20, None)])
+def test_bulk_samplers_equal_their_one_at_a_time_loops(strategy, n, m, want, n_excl, k):
+    """Sizes beyond the fixtures (several blocks, rejected words, exhausted attempt budgets): same list, same state of
+    both generators as the restated per-attempt loops — which the fixtures above hold against the reference."""
+    import generation_data as G
+    X = torch.randn(n, m, generator=torch.Generator().manual_seed(n + m))
+    probs = G._popularity_probs(m, "zipf", 1.5)
+    serial = {"proximity": lambda w, e: G._choose_items_by_proximity_serial(X, w, e, k),
+              "top_k": lambda w, e: G._choose_items_top_k_serial(X, w, e, k),
+              "popularity": lambda w, e: G._choose_items_by_popularity_serial(n, m, probs, w, e)}[strategy]
+    bulk = {"proximity": lambda w, e: G.choose_items_by_proximity(X, w, e, k),
+            "top_k": lambda w, e: G.choose_items_top_k(X, w, e, k),
+            "popularity": lambda w, e: G.choose_items_by_popularity(X, w, e)}[strategy]
+    torch.manual_seed(1)
+    np.random.seed(1)
+    excl = set(serial(n_excl, set()))
+    torch.manual_seed(want)
+    np.random.seed(want)
+    expect = serial(want, excl)
+    state = (torch.get_rng_state(), np.random.get_state())
+    torch.manual_seed(want)
+    np.random.seed(want)
+    got = bulk(want, excl)
+    assert got == expect
+    assert torch.equal(torch.get_rng_state(), state[0])
+    now = np.random.get_state()
+    assert np.array_equal(now[1], state[1][1]) and now[2] == state[1][2]
+
+
+def test_svd_sampler_draws_distinct_allowed_triplets_from_the_top_sets():
+    """generation_data.py:131-179 (unseeded numpy Generator: no draw order to keep): every triplet comes from the
+    top-30 % users / items by projection norm, is unique, respects `exclude`, and a request larger than the support
+    ends at the reference's 5x attempt budget with its warning."""
+    import generation_data as G
+    import scipy.sparse.linalg as spla
+    torch.manual_seed(5)
+    X = torch.randn(60, 8) @ torch.randn(8, 90)
+    want = 1500
+    got = G.choose_items_by_svd_projection(X, want, set())
+    assert len(got) == len(set(got)) == want and all(i != j for _, i, j in got)
+    rank = int(want / (60 * 90) * 90)
+    Us, S, Vt = spla.svds(X.numpy(), k=rank)
+    top_u = set(np.argsort(np.linalg.norm(Us * S, axis=1))[-18:].tolist())
+    top_i = set(np.argsort(np.linalg.norm(Vt.T * S, axis=1))[-27:].tolist())
+    assert {u for u, _, _ in got} <= top_u and {i for _, i, _ in got} | {j for _, _, j in got} <= top_i
+    more = G.choose_items_by_svd_projection(X, want, set(got))
+    assert not set(more) & set(got)
+
+
 def test_dataset_rows_and_lazy_data_list():
     import structure as S
     from mfcd.batching import dataset_records
