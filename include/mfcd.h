@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MFCD_ABI_VERSION 3
+#define MFCD_ABI_VERSION 4
 
 #define MFCD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, d out of range)   */
 #define MFCD_EWORKSPACE (-2) /* workspace smaller than mfcd_*_workspace_bytes says             */
@@ -409,6 +409,53 @@ int mfcd_generate_labels(const int32_t *triplets, int64_t T, const float *X, int
 int mfcd_spearman_max_columns(void);
 int mfcd_spearman_rows(const float *A, int64_t lda, const float *X, int64_t ldx, int rows, int m,
                        double *rho, void *stream);
+
+/*
+ * Triplet sampling on the device (replaces the per-attempt rejection loops of generation_data.py:16-224
+ * — choose_items_random 16-26, _by_proximity 29-43, _by_margin 46-84, _by_variance 87-99, _by_popularity 103-128,
+ * _by_svd_projection 164-174 (the draw loop), _top_k 205-219).  One call evaluates `attempts` attempts
+ * [attempt0, attempt0 + attempts) of the law and keeps what the reference's loop keeps: the first `want` triplets, in
+ * attempt order, that pass the law's filter, are not among `barred_keys` and were not produced by an earlier attempt.
+ * A triplet's key is (u * m + i) * m + j (int64); barred_keys holds the caller's `exclude` set plus the keys returned
+ * by earlier calls of the same request, in any order.
+ *
+ *   law        MFCD_LAW_UNIFORM   u ~ U[0,n), i, j ~ U[0,m)                         (random; margin with use_margin)
+ *              MFCD_LAW_ITEM_CDF  i, j from the item law whose cumulative sums are cdf[m] (f64, cdf[m-1] == 1):
+ *                                 pair_rule 0 = numpy choice(m, size=2, replace=False, p) (popularity),
+ *                                 pair_rule 1 = sequential draw without replacement (torch.multinomial; variance)
+ *              MFCD_LAW_LISTS     i = list_i[u * list_row_stride + U[0,k)], j likewise from list_j; pair_rule 1 makes
+ *                                 the two positions distinct (top_k, svd); list_row_stride = k for per-user tables
+ *                                 (proximity, top_k), 0 for one list shared by all users (svd)
+ *   users      NULL (u over all n users) or n_users user ids to draw u from (svd: the top users)
+ *   use_margin keep only |X[u][i] - X[u][j]| <= margin (fp32 difference, as generation_data.py:72-73); X dense
+ *              [n][m] fp32, or NULL with the factors A [n][dx], B [m][dx] of X = A B^T
+ * Attempts with i == j are rejected in every law.  Outputs (device): triplets_out [want][3] int32 and keys_out [want]
+ * in attempt order; counts_out[0] = triplets written (<= want), counts_out[1] = attempts consumed (the attempt that
+ * completed the request + 1, or `attempts`).  Randomness: Philox4x32-10 keyed by `seed`, counter = (attempt index, draw
+ * group): reproducible, independent of launch geometry and of how a request is cut into calls; NOT the reference's
+ * generator streams — distributional parity (the seeded host forms in generation_data.py replay those).
+ * attempts + n_barred < 2^32 - 1.  workspace: mfcd_sample_workspace_bytes(attempts, n_barred) bytes (0 = bad sizes).
+ */
+#define MFCD_LAW_UNIFORM 0
+#define MFCD_LAW_ITEM_CDF 1
+#define MFCD_LAW_LISTS 2
+
+typedef struct mfcd_sampler {
+    int32_t law, n, m, pair_rule;
+    const double *cdf;
+    const int32_t *list_i, *list_j;
+    int32_t k, list_row_stride;
+    const int32_t *users;
+    int32_t n_users, use_margin;
+    double margin;
+    const float *X, *A, *B;
+    int32_t dx, reserved;
+} mfcd_sampler;
+
+size_t mfcd_sample_workspace_bytes(int64_t attempts, int64_t n_barred);
+int mfcd_sample_triplets(const mfcd_sampler *law, const int64_t *barred_keys, int64_t n_barred, int64_t attempt0,
+                         int64_t attempts, uint64_t seed, int64_t want, int32_t *triplets_out, int64_t *keys_out,
+                         int64_t *counts_out, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

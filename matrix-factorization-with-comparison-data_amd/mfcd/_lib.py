@@ -60,6 +60,8 @@ SIGNATURES = {
     "mfcd_uvt_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mfcd_generate_labels": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _dbl, _i32, _i32, ctypes.c_uint64, _vp,
                                      _vp]),
+    "mfcd_sample_workspace_bytes": (_sz, [_i64, _i64]),
+    "mfcd_sample_triplets": (_i32, [_vp, _vp, _i64, _i64, _i64, ctypes.c_uint64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_spearman_max_columns": (_i32, []),
     "mfcd_spearman_rows": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
 }
@@ -75,6 +77,15 @@ class TrainPlan(ctypes.Structure):
                                                "resident_lookahead", "fast_math", "streaming_vec",
                                                "streaming_chunks", "streaming_blocks", "device_cus")] + \
                [("reserved", ctypes.c_int32 * 6)]
+
+
+class Sampler(ctypes.Structure):
+    """mfcd_sampler of include/mfcd.h."""
+    _fields_ = [("law", ctypes.c_int32), ("n", ctypes.c_int32), ("m", ctypes.c_int32), ("pair_rule", ctypes.c_int32),
+                ("cdf", _vp), ("list_i", _vp), ("list_j", _vp), ("k", ctypes.c_int32),
+                ("list_row_stride", ctypes.c_int32), ("users", _vp), ("n_users", ctypes.c_int32),
+                ("use_margin", ctypes.c_int32), ("margin", _dbl), ("X", _vp), ("A", _vp), ("B", _vp),
+                ("dx", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _lib = None
@@ -97,7 +108,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if lib.mfcd_abi_version() != 3:
+        if lib.mfcd_abi_version() != 4:
             raise MfcdError("libmfcd_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -22,6 +22,7 @@ from generation_data import *  # noqa: F401,F403  (ref:17 re-exports every sampl
 import generation_data as _gd
 from mfcd import engine as _engine
 from mfcd import metrics as _metrics
+from mfcd import sampling as _sampling
 
 if torch.get_num_threads() > 16:  # imported after torch: keep the host-side pool small (GPU boxes expose 100s of cores)
     torch.set_num_threads(4)
@@ -247,11 +248,29 @@ _STRATEGIES = {
 }
 
 
+_SAMPLER_DEVICE = None
+
+
+def set_sampler_device(device):
+    """Extension (not in the reference): draw triplets ON `device` (a GPU; include/mfcd.h mfcd_sample_triplets) from now
+    on for the strategies that have a device law (random, margin, popularity, variance, proximity, top_k, svd); the
+    others (cluster, user_similarity — "Not used" in the reference's own comments) and None (default) use the host
+    samplers, which consume torch's / numpy's generators exactly like the reference."""
+    global _SAMPLER_DEVICE
+    if device is not None:
+        _need_gpu(device)
+    _SAMPLER_DEVICE = None if device is None else torch.device(device)
+
+
 def get_triplets_from_X(X, num_triplets, strategy="random", exclude=None, popularity_method="zipf", alpha=1.5,
                         n_clusters=10):
     """ref:533-588 → set of unique (u, i, j)."""
     if strategy not in _STRATEGIES:
         raise ValueError(f"Unknown triplet sampling strategy: {strategy}")
+    if _SAMPLER_DEVICE is not None and strategy in _sampling.DEVICE_STRATEGIES:
+        kw = dict(popularity_method=popularity_method, alpha=alpha) if strategy == "popularity" else {}
+        rows = _sampling.sample_triplets(X, num_triplets, strategy, exclude, device=_SAMPLER_DEVICE, **kw).cpu().numpy()
+        return set(zip(rows[:, 0].tolist(), rows[:, 1].tolist(), rows[:, 2].tolist()))
     found = _STRATEGIES[strategy](X, num_triplets, exclude or set(), popularity_method=popularity_method,
                                   alpha=alpha, n_clusters=n_clusters)
     return set(found)

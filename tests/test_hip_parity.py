@@ -978,6 +978,170 @@ def test_device_label_generation_follows_the_btl_law(dev):
 
 
 # --------------------------------------------------------------------------------------------------
+# (g2) SURVEY 8f N2: triplet sampling on the device
+# --------------------------------------------------------------------------------------------------
+def _chi2_ok(counts, probs, label, z=5.0):
+    """Pearson chi-square of observed counts against a law, accepted within z sigma of its mean (dof, var 2 dof)."""
+    counts, probs = np.asarray(counts, dtype=np.float64), np.asarray(probs, dtype=np.float64)
+    keep = probs * counts.sum() >= 5
+    c = np.append(counts[keep], counts[~keep].sum())
+    q = np.append(probs[keep], probs[~keep].sum())
+    c, q = c[q > 0], q[q > 0]
+    stat = (((c - q * c.sum()) ** 2) / (q * c.sum())).sum()
+    dof = len(c) - 1
+    assert stat < dof + z * np.sqrt(2 * dof) + 10, (label, stat, dof)
+
+
+def test_device_samplers_follow_the_laws_of_the_reference_loops(dev, capsys):
+    """mfcd_sample_triplets (generation_data.py:16-224 on the device).  Philox stream, so parity is DISTRIBUTIONAL, as
+    for the labels: per strategy the structural contract of the reference loop (unique, i != j, inside the strategy's
+    candidate sets, `exclude` respected, attempt budgets and warnings) and chi-square tests of the marginals against the
+    law the loop draws from — for popularity the law of numpy's choice(size=2, replace=False, p), computed in closed
+    form; the host samplers, which replay the reference's generators, pass the same checks."""
+    import generation_data as gd
+    from mfcd import sampling
+    torch.manual_seed(3)
+    n, m = 6000, 40
+    X = torch.randn(n, m)
+    Xd = X.to(dev)
+
+    def draw(strategy, want, exclude=None, seed=7, X_=Xd, **kw):
+        rows = sampling.sample_triplets(X_, want, strategy, exclude, device=dev, seed=seed, **kw).cpu().numpy()
+        assert rows.dtype == np.int32 and rows.ndim == 2 and rows.shape[1] == 3
+        assert len({tuple(r) for r in rows.tolist()}) == rows.shape[0], strategy          # distinct
+        nn, mm = X_.shape
+        assert (rows[:, 1] != rows[:, 2]).all() and rows.min() >= 0
+        assert rows[:, 0].max() < nn and rows[:, 1:].max() < mm
+        return rows
+
+    # random: uniform marginals, exclusion, reproducibility, independence of how the request is cut into blocks
+    r = draw("random", 50000)
+    assert r.shape[0] == 50000
+    _chi2_ok(np.bincount(r[:, 1], minlength=m), np.full(m, 1 / m), "random i")
+    _chi2_ok(np.bincount(r[:, 2], minlength=m), np.full(m, 1 / m), "random j")
+    _chi2_ok(np.bincount(r[:, 0] % 97, minlength=97), np.bincount(np.arange(n) % 97) / n, "random u")
+    assert np.array_equal(r, draw("random", 50000)) and not np.array_equal(r, draw("random", 50000, seed=8))
+    assert np.array_equal(r[:1000], draw("random", 1000))              # attempt order: a shorter request is a prefix
+    barred = {tuple(t) for t in r[:20000].tolist()}
+    r2 = draw("random", 30000, exclude=barred)
+    assert not ({tuple(t) for t in r2.tolist()} & barred)
+    small = torch.randn(5, 4)
+    full = draw("random", 60, X_=small.to(dev))                        # the whole support: 5 * 4 * 3
+    assert full.shape[0] == 60
+    with pytest.raises(ValueError):
+        draw("random", 61, X_=small.to(dev))                           # the reference would spin forever
+
+    # popularity: numpy's choice(size=2, replace=False, p): a ~ p; b ~ p, redrawn from p without a only if b == a
+    pm = gd._popularity_probs(m, "zipf", 1.5)
+    r = draw("popularity", 40000, popularity_method="zipf", alpha=1.5)
+    assert r.shape[0] == 40000
+    pair = np.outer(pm, pm) * (1 + (pm / (1 - pm))[:, None])
+    np.fill_diagonal(pair, 0.0)
+    assert abs(pair.sum() - 1) < 1e-12
+    # kept triplets are DISTINCT draws: with n = 6000 users, 40 000 of them, duplicates of the head pair are frequent,
+    # so the marginals are compared on the attempt law restricted to first occurrences: use few draws per (i, j) cell
+    r_few = draw("popularity", 3000, popularity_method="zipf", alpha=1.5, seed=11)
+    _chi2_ok(np.bincount(r_few[:, 1], minlength=m), pair.sum(axis=1), "popularity i")
+    _chi2_ok(np.bincount(r_few[:, 2], minlength=m), pair.sum(axis=0), "popularity j")
+    host = np.asarray(gd.choose_items_by_popularity(X, 3000, set()))
+    _chi2_ok(np.bincount(host[:, 2], minlength=m), pair.sum(axis=0), "popularity j (host form)")
+
+    # variance: sequential draw without replacement from var / sum(var)
+    pv = torch.var(X, dim=0).double().numpy()
+    pv /= pv.sum()
+    r = draw("variance", 3000)
+    seq = np.outer(pv, pv) / (1 - pv)[:, None]
+    np.fill_diagonal(seq, 0.0)
+    _chi2_ok(np.bincount(r[:, 1], minlength=m), seq.sum(axis=1), "variance i")
+    _chi2_ok(np.bincount(r[:, 2], minlength=m), seq.sum(axis=0), "variance j")
+
+    # proximity: i among the user's k best, j among the k worst, positions uniform
+    k = 8
+    best = torch.topk(X, k, dim=1)[1].numpy()
+    worst = torch.topk(-X, k, dim=1)[1].numpy()
+    r = draw("proximity", 30000, k=k)
+    pos_i = (best[r[:, 0]] == r[:, 1:2]).argmax(axis=1)
+    pos_j = (worst[r[:, 0]] == r[:, 2:3]).argmax(axis=1)
+    assert (best[r[:, 0], pos_i] == r[:, 1]).all() and (worst[r[:, 0], pos_j] == r[:, 2]).all()
+    _chi2_ok(np.bincount(pos_i, minlength=k), np.full(k, 1 / k), "proximity position i")
+    _chi2_ok(np.bincount(pos_j, minlength=k), np.full(k, 1 / k), "proximity position j")
+
+    # top_k: both among the k best (k = max(5, m // 10)), ordered pairs of distinct positions uniform; 3x budget
+    k = 5
+    best = torch.topk(X, k, dim=1)[1].numpy()
+    r = draw("top_k", 30000)
+    pos_i = (best[r[:, 0]] == r[:, 1:2]).argmax(axis=1)
+    pos_j = (best[r[:, 0]] == r[:, 2:3]).argmax(axis=1)
+    assert (best[r[:, 0], pos_i] == r[:, 1]).all() and (best[r[:, 0], pos_j] == r[:, 2]).all()
+    cell = pos_i * k + pos_j
+    probs = np.full(k * k, 1 / (k * (k - 1)))
+    probs[::k + 1] = 0
+    _chi2_ok(np.bincount(cell, minlength=k * k), probs, "top_k positions")
+    capsys.readouterr()
+    short = draw("top_k", 500, X_=torch.randn(6, 30).to(dev))          # support 6 * 5 * 4 = 120 < 500
+    assert short.shape[0] <= 120 and "Only" in capsys.readouterr().out
+
+    # margin: every kept pair within the adaptive margin, acceptance rate as the host form's
+    want = 4000
+    r = draw("margin", want)
+    head = X[:10].numpy()
+    margin = np.mean(head.max(axis=1) - head.min(axis=1)) * want / (n * m)
+    xs = X.numpy()
+    assert (np.abs(xs[r[:, 0], r[:, 1]] - xs[r[:, 0], r[:, 2]]) <= margin).all() and r.shape[0] == want
+    FX = gd.FactoredMatrix(torch.randn(n, 6), torch.randn(m, 6))
+    capsys.readouterr()
+    rf = sampling.sample_triplets(FX, 200000, "margin", None, device=dev, seed=5, max_attempts=100000).cpu().numpy()
+    out = capsys.readouterr().out
+    assert "Only" in out and "after 100000 attempts" in out            # budget in blocks of 500, the reference's message
+    head = FX.rows(0, 10)
+    margin = np.mean(head.max(axis=1) - head.min(axis=1)) * 200000 / (n * m)
+    assert 0 < rf.shape[0] < 200000 and (np.abs(FX.pair_diff(rf[:, 0], rf[:, 1], rf[:, 2])) <= margin * (1 + 1e-5)).all()
+
+    # svd: users / items from the top-30 % projection-norm sets, 5x budget
+    Xs = (torch.randn(200, 6) @ torch.randn(6, 90))
+    r = draw("svd", 1500, X_=Xs.to(dev))
+    import scipy.sparse.linalg as spla
+    Us, Sv, Vt = spla.svds(Xs.numpy(), k=int(1500 / (200 * 90) * 200))
+    top_u = set(np.argsort(np.linalg.norm(Us * Sv, axis=1))[-60:].tolist())
+    top_i = set(np.argsort(np.linalg.norm(Vt.T * Sv, axis=1))[-27:].tolist())
+    assert r.shape[0] == 1500 and set(r[:, 0].tolist()) <= top_u and set(r[:, 1].tolist()) | set(r[:, 2].tolist()) <= top_i
+
+
+def test_device_sampler_feeds_the_reference_pipeline(dev):
+    """structure.set_sampler_device + set_label_device: split_dataset_from_triplets (structure.py:666-742) with triplets
+    and labels made on the GPU keeps the split sizes, the >= 500 test rows top-up, disjoint splits, and trains."""
+    import structure as S
+    n, m, d = 400, 300, 8
+    X = S.generate_X(n, m, d, dev)
+    S.set_sampler_device(dev)
+    S.set_label_device(dev)
+    try:
+        torch.manual_seed(0)
+        for strategy in ("random", "popularity", "top_k", "proximity", "margin"):
+            tr, va, te = S.split_dataset_from_triplets(X, 3000, scale=1.0, K=2, strategy=strategy)
+            rows = [np.asarray(ld.dataset.data)[:, :3].astype(np.int64) for ld in (tr, va, te)]
+            sets = [{tuple(r) for r in x.tolist()} for x in rows]
+            total = sum(len(s_) for s_ in sets)
+            assert not (sets[0] & sets[1]) and not (sets[0] & sets[2]) and not (sets[1] & sets[2]), strategy
+            assert len(te.dataset) >= 500 and total <= 3000 + 250, strategy
+            if strategy != "margin":
+                assert len(sets[0]) == 2400 and len(sets[1]) == 300, strategy
+        torch.manual_seed(1)
+        a = S.get_triplets_from_X(X, 500, strategy="random")
+        torch.manual_seed(1)
+        assert a == S.get_triplets_from_X(X, 500, strategy="random")   # seeded through torch's global generator
+        assert isinstance(a, set) and all(type(v) is int for t in a for v in t)
+        tr, va, te = S.split_dataset_from_triplets(X, 6000, K=1, strategy="random")
+    finally:
+        S.set_sampler_device(None)
+        S.set_label_device(None)
+    model = S.MatrixFactorization(n, m, d).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=1e-5)
+    tl, vl = S.train_model(model, tr, va, opt, dev, num_epochs=3)
+    assert np.isfinite(tl).all() and tl[-1] < tl[0]
+
+
+# --------------------------------------------------------------------------------------------------
 # (h) VERDICT r1 item 5: row-sharded state, batch 64 (strong scaling), results equal to one GPU
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("world,n,m,d,N", [(w, *shp) for w in (1, 2, 3, 8) for shp in

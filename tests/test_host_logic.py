@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     declared.discard("mfcd_sample")
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.load()  # binds each symbol; AttributeError if one is missing
-    assert L.mfcd_abi_version() == 3
+    assert L.mfcd_abi_version() == 4
     assert L.mfcd_error_string(0).decode() == "success"
     assert L.mfcd_error_string(-1).decode().startswith("mfcd:")
     # pure host helpers may be called without a GPU
