@@ -137,6 +137,7 @@ int mfcd_set_resident_math(int fast);
 #define MFCD_TUNE_UVT_TARGET_WGS 9      /* UV^T pass: workgroups the column split aims for (default 512)       */
 #define MFCD_TUNE_UVT_SPLIT 11          /* UV^T pass, d in {32, 64, 128}: 1 (default) = bf16x3 split product on the bf16 matrix pipe, 0 = fp32 MFMA */
 #define MFCD_TUNE_RANK_SORT 12          /* Spearman kernel's sort: 1 (default) = block radix sort, 0 = bitonic network in LDS */
+#define MFCD_TUNE_SHARD_PIPELINE 13     /* row-sharded native loop: 1 (default) = exchange of batch k+1 under step k, 0 = strict chain */
 #define MFCD_TUNE_UVT_MIN_STAGES 10     /* UV^T pass: column stages a workgroup sweeps at least (default 8)    */
 int mfcd_set_tuning(int key, int64_t value);
 
@@ -321,7 +322,19 @@ int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, float *mV, flo
  *                                        mfcd_dp_comm_create); table pointers are the rank's SHARDS.
  *                                        comm == NULL: the pointers are the FULL tables and this process plays every
  *                                        rank in turn (single-process rehearsal of any world size).
- * xbuf / workspace: mfcd_shard_workspace_bytes(N, B, d) bytes (the buffer comes first, 3*B*d floats).
+ *   mfcd_shard_pack_ahead                PIPELINED exchange (round 3): the rows of the NEXT batch as they will be
+ *                                        after the step `step` that has not run yet — a row the current batch does
+ *                                        not name changes in that step by the dense update with a zero sparse
+ *                                        gradient, a pure function of its (p, m, v), computed here with the step
+ *                                        kernel's own arithmetic (bit-identical) — so the all-reduce of batch k+1 can
+ *                                        run underneath step k.  Only legal when no row of the next batch is named
+ *                                        by the current one:
+ *   mfcd_shard_collisions                flags[k] (uint8, device) = 1 when batch k+1 shares a row with batch k.
+ * mfcd_shard_train_steps takes the pipelined chain by default (MFCD_TUNE_SHARD_PIPELINE 0 restores pack -> all-reduce
+ * -> step on one stream): collectives on a side stream, two exchange buffers, strict chain only across colliding
+ * pairs; it reads the collision flags on the host once per call (its one host wait).  Results are bit-identical in
+ * both chains.
+ * xbuf / workspace: mfcd_shard_workspace_bytes(N, B, d) bytes (the buffers come first, 3*B*d floats each).
  * u_lo..v_hi are GLOBAL row bounds of the shard; batch records name global rows.
  */
 int mfcd_shard_rows(int rows, int rank, int world, int *lo, int *hi);
@@ -332,6 +345,11 @@ int mfcd_shard_apply(float *U_shard, float *V_shard, float *mU, float *vU, float
                      const mfcd_sample *batch, int Bk, int B, const float *xbuf, int64_t step, int d, int u_lo,
                      int u_hi, int v_lo, int v_hi, double lr, double beta1, double beta2, double eps,
                      double weight_decay, float *loss_terms, void *stream);
+int mfcd_shard_collisions(const mfcd_sample *samples, int64_t N, int B, uint8_t *flags_dev, void *stream);
+int mfcd_shard_pack_ahead(const float *U_shard, const float *V_shard, const float *mU, const float *vU,
+                          const float *mV, const float *vV, const mfcd_sample *next_batch, int Bk, int B, int64_t step,
+                          int d, int u_lo, int u_hi, int v_lo, int v_hi, double lr, double beta1, double beta2,
+                          double eps, double weight_decay, float *xbuf, void *stream);
 int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
                            const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0, int n,
                            int m, int d, double lr, double beta1, double beta2, double eps, double weight_decay,

@@ -695,6 +695,10 @@ extern "C" int mfcd_set_tuning(int key, int64_t value)
             if (value < 0 || value > 0x7fffffff) return MFCD_EINVAL;
             t.short_call_steps = (int)value;
             return 0;
+        case MFCD_TUNE_SHARD_PIPELINE:
+            if (value != 0 && value != 1) return MFCD_EINVAL;
+            t.shard_pipeline = (int)value;
+            return 0;
         default: return MFCD_EINVAL;
     }
 }
@@ -1340,6 +1344,65 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const float *__restrict
     for (int k = lane; k < d; k += MFCD_WAVE) dst[k] = src ? src[k] : 0.0f;
 }
 
+// Exchange rows of the NEXT batch, rolled forward over the step that is about to run (the look-ahead rule of the
+// resident form): a row that the current batch does not touch changes in that step by the dense update with
+// a zero sparse gradient alone, a pure function of its (p, m, v) — so its value AFTER the step can be put on the wire
+// BEFORE the step runs, and the collective of batch k+1 overlaps the step of batch k.  Same adam_update, same operation
+// order as the step kernel: the rolled value equals the in-place one bit for bit (rehearsal tests).  The caller
+// guarantees that no row of `next` is named by the current batch (mfcd_shard_collisions).
+__global__ __launch_bounds__(256) void shard_pack_ahead_kernel(const float *__restrict__ Us, const float *__restrict__ Vs,
+                                                               const float *__restrict__ mU, const float *__restrict__ vU,
+                                                               const float *__restrict__ mV, const float *__restrict__ vV,
+                                                               const mfcd_sample *__restrict__ next, int Bk, int Bcap,
+                                                               int d, int u_off, int nu, int v_off, int nv, AdamConst ac,
+                                                               float *__restrict__ xbuf, int merge)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // (role, t)
+    if (w >= 3 * Bcap) return;
+    const int role = w / Bcap, t = w - role * Bcap;
+    int64_t src = -1;
+    if (t < Bk) {
+        const mfcd_sample s = next[t];
+        const int row = role == 0 ? s.u - u_off : (role == 1 ? s.i : s.j) - v_off;
+        if (row >= 0 && row < (role == 0 ? nu : nv)) src = (int64_t)row * d;
+    }
+    if (merge && src < 0) return;
+    float *dst = xbuf + (int64_t)w * d;
+    const float *P = role == 0 ? Us : Vs, *M1 = role == 0 ? mU : mV, *M2 = role == 0 ? vU : vV;
+    for (int k = lane; k < d; k += MFCD_WAVE) {
+        float v = 0.0f;
+        if (src >= 0) {
+            float p = P[src + k], m1 = M1[src + k], m2 = M2[src + k];
+            adam_update(p, m1, m2, 0.0f, ac.st, ac.sc);
+            v = p;
+        }
+        dst[k] = v;
+    }
+}
+
+// flags[k] = 1 when batch k+1 names a row that batch k names too (same table), 0 otherwise and for the last batch.
+__global__ __launch_bounds__(256) void shard_collisions_kernel(const mfcd_sample *__restrict__ samples, int64_t N, int B,
+                                                               int64_t nsteps, uint8_t *__restrict__ flags)
+{
+    const int64_t k = blockIdx.x;
+    __shared__ int hit;
+    if (threadIdx.x == 0) hit = 0;
+    __syncthreads();
+    if (k + 1 < nsteps) {
+        const int64_t o0 = k * B, o1 = (k + 1) * B;
+        const int b0 = (int)((N - o0) < B ? (N - o0) : B), b1 = (int)((N - o1) < B ? (N - o1) : B);
+        int mine = 0;
+        for (int64_t pr = threadIdx.x; pr < (int64_t)b0 * b1 && !mine; pr += 256) {
+            const mfcd_sample a = samples[o0 + pr / b1], b = samples[o1 + pr % b1];
+            mine = (a.u == b.u) | (a.i == b.i) | (a.i == b.j) | (a.j == b.i) | (a.j == b.j);
+        }
+        if (mine) hit = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) flags[k] = (uint8_t)hit;
+}
+
 void shard_range(int rows, int rank, int world, int *lo, int *hi)
 {
     *lo = (int)((int64_t)rows * rank / world);
@@ -1375,7 +1438,36 @@ extern "C" int mfcd_shard_rows(int rows, int rank, int world, int *lo, int *hi)
 extern "C" size_t mfcd_shard_workspace_bytes(int64_t N, int B, int d)
 {
     if (N < 0 || B <= 0 || d <= 0) return 0;
-    return shard_xbuf_bytes(B, d) + align256(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    const size_t nsteps = (size_t)((N + B - 1) / B);
+    return 2 * shard_xbuf_bytes(B, d) + align256(sizeof(float) * (size_t)(N > 0 ? N : 1)) + align256(nsteps + 1);
+}
+
+extern "C" int mfcd_shard_collisions(const mfcd_sample *samples, int64_t N, int B, uint8_t *flags_dev, void *stream)
+{
+    if (N < 0 || B <= 0) return MFCD_EINVAL;
+    if (N == 0) return 0;
+    if (!samples || !flags_dev) return MFCD_EINVAL;
+    const int64_t nsteps = (N + B - 1) / B;
+    hipLaunchKernelGGL(shard_collisions_kernel, dim3((unsigned)nsteps), dim3(256), 0, (hipStream_t)stream, samples, N, B,
+                       nsteps, flags_dev);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mfcd_shard_pack_ahead(const float *U_shard, const float *V_shard, const float *mU, const float *vU,
+                                     const float *mV, const float *vV, const mfcd_sample *next_batch, int Bk, int B,
+                                     int64_t step, int d, int u_lo, int u_hi, int v_lo, int v_hi, double lr, double beta1,
+                                     double beta2, double eps, double weight_decay, float *xbuf, void *stream)
+{
+    if (!next_batch || !xbuf || Bk < 0 || B <= 0 || Bk > B || d <= 0 || d > MFCD_MAX_D || u_hi < u_lo || v_hi < v_lo ||
+        step < 1)
+        return MFCD_EINVAL;
+    if ((u_hi > u_lo && (!U_shard || !mU || !vU)) || (v_hi > v_lo && (!V_shard || !mV || !vV))) return MFCD_EINVAL;
+    const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step);
+    hipLaunchKernelGGL(shard_pack_ahead_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, U_shard, V_shard,
+                       mU, vU, mV, vV, next_batch, Bk, B, d, u_lo, u_hi - u_lo, v_lo, v_hi - v_lo, ac, xbuf, 0);
+    MFCD_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int mfcd_shard_pack(const float *U_shard, const float *V_shard, const mfcd_sample *batch, int Bk, int B,
@@ -1435,40 +1527,132 @@ extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, 
         if (!R->ok || !R->AllReduce) return MFCD_ERCCL;
     }
     hipStream_t st = (hipStream_t)stream;
-    float *xbuf = (float *)workspace;
-    float *terms = (float *)((char *)workspace + shard_xbuf_bytes(B, d));
+    const size_t xb = shard_xbuf_bytes(B, d);
+    float *xbufs[2] = {(float *)workspace, (float *)((char *)workspace + xb)};
+    float *terms = (float *)((char *)workspace + 2 * xb);
+    uint8_t *flags_dev = (uint8_t *)((char *)terms + align256(sizeof(float) * (size_t)N));
     const int64_t nsteps = (N + B - 1) / B;
     // with a communicator the table pointers are this rank's SHARDS; without one they are the FULL tables and this
     // process plays every rank in turn (single-process rehearsal of any world size; exact, the protocol is the same)
     const int r0 = comm ? rank : 0, r1 = comm ? rank + 1 : world;
-    for (int64_t k = 0; k < nsteps; ++k) {
+    auto range = [&](int r, int &ul, int &uh, int &vl, int &vh, int64_t &uo, int64_t &vo) {
+        shard_range(n, r, world, &ul, &uh);
+        shard_range(m, r, world, &vl, &vh);
+        uo = comm ? 0 : (int64_t)ul * d;
+        vo = comm ? 0 : (int64_t)vl * d;
+    };
+    // rows of batch k as they are NOW into xbuf (after step k-1 has run)
+    auto pack_now = [&](int64_t k, float *xbuf) -> int {
         const int64_t off = k * B;
         const int Bk = (int)((N - off) < B ? (N - off) : B);
         for (int r = r0; r < r1; ++r) {
             int ul, uh, vl, vh;
-            shard_range(n, r, world, &ul, &uh);
-            shard_range(m, r, world, &vl, &vh);
-            const int64_t uo = comm ? 0 : (int64_t)ul * d, vo = comm ? 0 : (int64_t)vl * d;
-            if (comm || r == r0) {
-                if (int rc = mfcd_shard_pack(U + uo, V + vo, samples + off, Bk, B, d, ul, uh, vl, vh, xbuf, stream))
-                    return rc;
-            } else {   // rehearsal: the other ranks' rows land on top of the first rank's zeros (disjoint ownership)
-                hipLaunchKernelGGL(shard_pack_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, st, U + uo, V + vo,
-                                   samples + off, Bk, B, d, ul, uh - ul, vl, vh - vl, xbuf, 1);
-            }
+            int64_t uo, vo;
+            range(r, ul, uh, vl, vh, uo, vo);
+            hipLaunchKernelGGL(shard_pack_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, st, U + uo, V + vo, samples + off, Bk,
+                               B, d, ul, uh - ul, vl, vh - vl, xbuf, (comm || r == r0) ? 0 : 1);
         }
-        if (comm && R->AllReduce(xbuf, xbuf, (size_t)3 * B * d, ncclUint32, ncclSum, (ncclComm_t)comm, st) != ncclSuccess)
-            return MFCD_ERCCL;
+        MFCD_HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    // rows of batch k+1 as they will be after step k, which has not run yet (no row shared with batch k)
+    auto pack_ahead = [&](int64_t k, float *xbuf) -> int {
+        const int64_t off = (k + 1) * B;
+        const int Bk = (int)((N - off) < B ? (N - off) : B);
+        const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step0 + k + 1);
         for (int r = r0; r < r1; ++r) {
             int ul, uh, vl, vh;
-            shard_range(n, r, world, &ul, &uh);
-            shard_range(m, r, world, &vl, &vh);
-            const int64_t uo = comm ? 0 : (int64_t)ul * d, vo = comm ? 0 : (int64_t)vl * d;
+            int64_t uo, vo;
+            range(r, ul, uh, vl, vh, uo, vo);
+            hipLaunchKernelGGL(shard_pack_ahead_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, st, U + uo, V + vo, mU + uo,
+                               vU + uo, mV + vo, vV + vo, samples + off, Bk, B, d, ul, uh - ul, vl, vh - vl, ac, xbuf,
+                               (comm || r == r0) ? 0 : 1);
+        }
+        MFCD_HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    auto apply = [&](int64_t k, const float *xbuf) -> int {
+        const int64_t off = k * B;
+        const int Bk = (int)((N - off) < B ? (N - off) : B);
+        for (int r = r0; r < r1; ++r) {
+            int ul, uh, vl, vh;
+            int64_t uo, vo;
+            range(r, ul, uh, vl, vh, uo, vo);
             if (int rc = mfcd_shard_apply(U + uo, V + vo, mU + uo, vU + uo, mV + vo, vV + vo, samples + off, Bk, B, xbuf,
                                           step0 + k + 1, d, ul, uh, vl, vh, lr, beta1, beta2, eps, weight_decay,
                                           r == r0 ? terms + off : nullptr, stream))
                 return rc;
         }
+        return 0;
+    };
+
+    if (!mfcd_detail::g_tune.shard_pipeline || nsteps < 2) {
+        // the strict chain: pack -> all-reduce -> step, one stream
+        for (int64_t k = 0; k < nsteps; ++k) {
+            if (int rc = pack_now(k, xbufs[0])) return rc;
+            if (comm && R->AllReduce(xbufs[0], xbufs[0], (size_t)3 * B * d, ncclUint32, ncclSum, (ncclComm_t)comm, st) !=
+                            ncclSuccess)
+                return MFCD_ERCCL;
+            if (int rc = apply(k, xbufs[0])) return rc;
+        }
+    } else {
+        // Pipelined exchange: where batch k+1 shares no row with batch k, its rows are packed AHEAD of step k (rolled
+        // forward over it) and their all-reduce runs on a side stream underneath step k; only the pairs of batches that
+        // do share a row keep the strict chain.  Which pairs those are is a property of the sample stream alone (the
+        // same on every rank): one kernel marks them, the host reads the marks once per call (the one host wait of this
+        // entry point; the enqueue pattern — hence the collective sequence of every rank — depends on them).
+        if (int rc = mfcd_shard_collisions(samples, N, B, flags_dev, stream)) return rc;
+        std::vector<uint8_t> collide((size_t)nsteps);
+        MFCD_HIP_TRY(hipMemcpyAsync(collide.data(), flags_dev, (size_t)nsteps, hipMemcpyDeviceToHost, st));
+        MFCD_HIP_TRY(hipStreamSynchronize(st));
+        hipStream_t cs = nullptr;
+        hipEvent_t packed[2] = {nullptr, nullptr}, reduced[2] = {nullptr, nullptr};
+        int rc = 0;
+        auto fail = [&](int code) { if (!rc) rc = code; };
+        if (comm) {
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return MFCD_EINVAL;
+            for (int e = 0; e < 2; ++e) {
+                if (hipEventCreateWithFlags(&packed[e], hipEventDisableTiming) != hipSuccess) fail(MFCD_EINVAL);
+                if (hipEventCreateWithFlags(&reduced[e], hipEventDisableTiming) != hipSuccess) fail(MFCD_EINVAL);
+            }
+        }
+        // the collective of the buffer just packed on `st`, on the side stream; `st` meets it again at wait_reduced
+        auto reduce_async = [&](int b) {
+            if (!comm || rc) return;
+            if (hipEventRecord(packed[b], st) != hipSuccess || hipStreamWaitEvent(cs, packed[b], 0) != hipSuccess)
+                return fail(MFCD_EINVAL);
+            if (R->AllReduce(xbufs[b], xbufs[b], (size_t)3 * B * d, ncclUint32, ncclSum, (ncclComm_t)comm, cs) != ncclSuccess)
+                return fail(MFCD_ERCCL);
+            if (hipEventRecord(reduced[b], cs) != hipSuccess) fail(MFCD_EINVAL);
+        };
+        auto wait_reduced = [&](int b) {
+            if (comm && !rc && hipStreamWaitEvent(st, reduced[b], 0) != hipSuccess) fail(MFCD_EINVAL);
+        };
+        if (!rc) fail(pack_now(0, xbufs[0]));
+        reduce_async(0);
+        for (int64_t k = 0; k < nsteps && !rc; ++k) {
+            const int cur = (int)(k & 1), nxt = cur ^ 1;
+            const bool more = k + 1 < nsteps, ahead = more && !collide[(size_t)k];
+            if (ahead) {                      // batch k+1 goes on the wire before step k runs
+                fail(pack_ahead(k, xbufs[nxt]));
+                reduce_async(nxt);
+            }
+            wait_reduced(cur);
+            if (!rc) fail(apply(k, xbufs[cur]));
+            if (more && !ahead) {             // a shared row: batch k+1 is packed from the updated state
+                if (!rc) fail(pack_now(k + 1, xbufs[nxt]));
+                reduce_async(nxt);
+            }
+        }
+        if (comm) {
+            // every collective was met by `st` (wait_reduced precedes each step), so nothing is pending on the side stream
+            for (int e = 0; e < 2; ++e) {
+                if (packed[e]) (void)hipEventDestroy(packed[e]);
+                if (reduced[e]) (void)hipEventDestroy(reduced[e]);
+            }
+            (void)hipStreamDestroy(cs);
+        }
+        if (rc) return rc;
     }
     if (loss_per_step) {
         hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, terms,

@@ -159,6 +159,7 @@ struct Tuning {
     int stream_chunks = 0;       // streaming form: 16-byte chunks per thread and array (0 = by table size)
     int short_call_steps = 3;    // "auto": calls of fewer steps than this stream (one launch per step) instead of
                                  // paying the persistent launch's fixed cost
+    int shard_pipeline = 1;      // row-sharded loop: 1 = exchange of batch k+1 under step k where no row is shared
 };
 extern Tuning g_tune;
 

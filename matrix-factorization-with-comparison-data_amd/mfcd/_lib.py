@@ -49,6 +49,8 @@ SIGNATURES = {
     "mfcd_shard_rows": (_i32, [_i32, _i32, _i32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mfcd_shard_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mfcd_shard_pack": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mfcd_shard_collisions": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "mfcd_shard_pack_ahead": (_i32, [_vp] * 7 + [_i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp]),
     "mfcd_shard_apply": (_i32, [_vp] * 7 + [_i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp]),
     "mfcd_shard_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
                                [_vp, _vp, _sz, _vp, _vp]),
@@ -68,7 +70,7 @@ SIGNATURES = {
 
 TUNE_KEYS = {"resident_q": 1, "resident_wpc": 2, "resident_lookahead": 3, "resident_lds_pad": 4,
              "resident_spin_limit": 5, "short_call_steps": 6, "uvt_wpe128": 7, "stream_chunks": 8,
-             "uvt_target_wgs": 9, "uvt_min_stages": 10, "uvt_split": 11, "rank_sort": 12}
+             "uvt_target_wgs": 9, "uvt_min_stages": 10, "uvt_split": 11, "rank_sort": 12, "shard_pipeline": 13}
 
 
 class TrainPlan(ctypes.Structure):

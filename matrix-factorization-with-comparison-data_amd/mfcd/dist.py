@@ -24,6 +24,7 @@ The compute steps go through a small backend object so that the sharding/collect
 exercised on CPU (gloo) by the tests, which inject an oracle-backed backend; the product backend is
 `HipCompute` (C-ABI calls, no fallback).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -191,6 +192,15 @@ class HipShardCompute:
                                           _lib.ptr(batch), batch.shape[0], B, s.d, s.u_lo, s.u_hi, s.v_lo, s.v_hi,
                                           _lib.ptr(xbuf), _lib.stream_ptr(self.dev)))
 
+    def pack_ahead(self, next_batch, B, xbuf, step, hyper):
+        """Rows of `next_batch` as they will be after optimiser step `step`, which has not run yet."""
+        s = self.s
+        p = lambda t: _lib.ptr(t) if t.numel() else None              # noqa: E731
+        lr, b1, b2, eps, wd = hyper
+        _lib.check(self.L.mfcd_shard_pack_ahead(p(s.U), p(s.V), p(s.mU), p(s.vU), p(s.mV), p(s.vV), _lib.ptr(next_batch),
+                                                next_batch.shape[0], B, step, s.d, s.u_lo, s.u_hi, s.v_lo, s.v_hi,
+                                                lr, b1, b2, eps, wd, _lib.ptr(xbuf), _lib.stream_ptr(self.dev)))
+
     def apply(self, batch, B, xbuf, step, hyper, terms):
         s = self.s
         p = lambda t: _lib.ptr(t) if t.numel() else None              # noqa: E731
@@ -200,23 +210,56 @@ class HipShardCompute:
                                            s.v_hi, lr, b1, b2, eps, wd, _lib.ptr(terms), _lib.stream_ptr(self.dev)))
 
 
-def train_steps_sharded(compute, stream, B, step0, hyper, group=None):
+def batch_collisions(records, B):
+    """flags[k] = True when batch k+1 names a row that batch k names too (same table) — what mfcd_shard_collisions
+    marks on the device; host form for callers that own the collective.  `records`: int [N, >=3] array of (u, i, j)."""
+    r = np.asarray(records)[:, :3]
+    nsteps = (r.shape[0] + B - 1) // B
+    flags = np.zeros(nsteps, dtype=bool)
+    for k in range(nsteps - 1):
+        a, b = r[k * B:(k + 1) * B], r[(k + 1) * B:(k + 2) * B]
+        flags[k] = bool(np.intersect1d(a[:, 0], b[:, 0]).size or np.intersect1d(a[:, 1:], b[:, 1:]).size)
+    return flags
+
+
+def train_steps_sharded(compute, stream, B, step0, hyper, group=None, pipelined=True):
     """Consume `stream` (int32 [N,4] records, identical on every rank) in batches of B — the reference's batch, NOT
     B*world — with the state sharded by rows over the group.  Per step: pack the owned rows of the batch, ONE
     all-reduce(sum) of the exchange buffer viewed as int32 (exact: one non-zero contributor per row), apply.
     Returns the fp32 tensor of per-step batch-mean losses (identical on every rank; no collective needed for them:
-    every rank holds every sample's rows).  `compute` provides new_xbuf / pack / apply (HipShardCompute; the CPU tests
-    inject an oracle-backed one)."""
+    every rank holds every sample's rows).  `compute` provides new_xbuf / pack / pack_ahead / apply (HipShardCompute;
+    the CPU tests inject an oracle-backed one).
+
+    pipelined (default): where batch k+1 shares no row with batch k its rows are packed AHEAD of step k, rolled
+    forward over it (`compute.pack_ahead`: the dense update with a zero sparse gradient is a pure function of a row's
+    p, m, v), and their all-reduce is in flight while step k runs; pairs of batches that share a row keep the strict
+    pack → all-reduce → step chain.  Same results bit for bit (the native loop mfcd_shard_train_steps does the same
+    with a side stream inside the library)."""
     N = stream.shape[0]
     nsteps = (N + B - 1) // B
     losses = torch.empty(nsteps, dtype=torch.float32, device=stream.device)
-    xbuf = compute.new_xbuf(B)
+    xbufs = [compute.new_xbuf(B), compute.new_xbuf(B)]
     terms = torch.empty(B, dtype=torch.float32, device=stream.device)
+    collide = batch_collisions(stream.cpu().numpy(), B) if pipelined else np.ones(max(nsteps, 1), dtype=bool)
+    batch_of = lambda k: stream[k * B:(k + 1) * B]                     # noqa: E731
+    reduce = lambda x: dist.all_reduce(x.view(torch.int32), op=dist.ReduceOp.SUM, group=group, async_op=True)  # noqa: E731
+    work = [None, None]
+    if nsteps:
+        compute.pack(batch_of(0), B, xbufs[0])
+        work[0] = reduce(xbufs[0])
     for k in range(nsteps):
-        batch = stream[k * B:(k + 1) * B]
-        compute.pack(batch, B, xbuf)
-        dist.all_reduce(xbuf.view(torch.int32), op=dist.ReduceOp.SUM, group=group)
-        compute.apply(batch, B, xbuf, step0 + k + 1, hyper, terms)
+        cur, nxt = k & 1, (k & 1) ^ 1
+        batch = batch_of(k)
+        more = k + 1 < nsteps
+        ahead = more and not collide[k]
+        if ahead:                                   # batch k+1 goes on the wire before step k runs
+            compute.pack_ahead(batch_of(k + 1), B, xbufs[nxt], step0 + k + 1, hyper)
+            work[nxt] = reduce(xbufs[nxt])
+        work[cur].wait()
+        compute.apply(batch, B, xbufs[cur], step0 + k + 1, hyper, terms)
+        if more and not ahead:                      # a shared row: batch k+1 is packed from the updated state
+            compute.pack(batch_of(k + 1), B, xbufs[nxt])
+            work[nxt] = reduce(xbufs[nxt])
         losses[k] = terms[: batch.shape[0]].sum() / batch.shape[0]   # ~1 ulp of the native loop's fixed-order mean
     return losses
 

@@ -172,6 +172,27 @@ class OracleShardCompute:
             if self.v_lo <= j < self.v_hi:
                 x[2, t] = self.V[j - self.v_lo]
 
+    def pack_ahead(self, next_batch, B, xbuf, step, hyper):
+        """mfcd_shard_pack_ahead: the next batch's rows rolled forward over step `step` (zero sparse gradient)."""
+        lr, b1, b2, eps, wd = hyper
+        x = xbuf.numpy().reshape(3, B, self.d)
+        x[:] = 0.0
+        r = next_batch.numpy()
+
+        def rolled(P, M1, M2, row):
+            p, m1, m2 = P[row:row + 1].copy(), M1[row:row + 1].copy(), M2[row:row + 1].copy()
+            self.orc.adam(p, m1, m2, np.zeros_like(p), step, lr=lr, betas=(b1, b2), eps=eps, wd=wd)
+            return p[0]
+        for t in range(r.shape[0]):
+            u, i, j = int(r[t, 0]), int(r[t, 1]), int(r[t, 2])
+            if self.u_lo <= u < self.u_hi:
+                x[0, t] = rolled(self.U, self.mU, self.vU, u - self.u_lo)
+            if self.v_lo <= i < self.v_hi:
+                x[1, t] = rolled(self.V, self.mV, self.vV, i - self.v_lo)
+            if self.v_lo <= j < self.v_hi:
+                x[2, t] = rolled(self.V, self.mV, self.vV, j - self.v_lo)
+        self.ahead_calls = getattr(self, "ahead_calls", 0) + 1
+
     def apply(self, batch, B, xbuf, step, hyper, terms):
         x = xbuf.numpy().reshape(3, B, self.d)
         r = batch.numpy()
@@ -200,7 +221,22 @@ class OracleShardCompute:
         terms[:Bk] = torch.from_numpy(term)
 
 
-def _shard_worker(rank, world, port, out_dir):
+SHARD_CASES = {"dense": (41, 30, 8, 16, 16 * 9 + 5),       # every pair of consecutive batches shares a row
+               "sparse": (900, 700, 8, 8, 8 * 40 + 3)}        # most pairs share none: the look-ahead exchange runs
+
+
+def _shard_inputs(case):
+    n, m, d, B, N = SHARD_CASES[case]
+    rng = np.random.default_rng(8)
+    U0 = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    V0 = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
+    u, i = rng.integers(0, n, N), rng.integers(0, m, N)
+    j = (i + 1 + rng.integers(0, m - 1, N)) % m
+    z = rng.integers(0, 2, N).astype(np.float64)
+    return n, m, d, B, N, U0, V0, u, i, j, z
+
+
+def _shard_worker(rank, world, port, out_dir, case):
     import sys
     for p in (ROOT, PKG):
         if p not in sys.path:
@@ -210,39 +246,41 @@ def _shard_worker(rank, world, port, out_dir):
     try:
         from mfcd import dist as mdist
         from mfcd.batching import pack_records
-        rng = np.random.default_rng(8)
-        n, m, d, B, N = 41, 30, 8, 16, 16 * 9 + 5
-        U0 = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
-        V0 = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
-        u, i = rng.integers(0, n, N), rng.integers(0, m, N)
-        j = (i + 1 + rng.integers(0, m - 1, N)) % m
-        z = rng.integers(0, 2, N).astype(np.float64)
+        n, m, d, B, N, U0, V0, u, i, j, z = _shard_inputs(case)
         stream = torch.from_numpy(pack_records(np.stack([u, i, j, z], 1), n, m))
-        comp = OracleShardCompute(U0, V0, rank, world, 1e-3, 1e-5)
-        losses = mdist.train_steps_sharded(comp, stream, B, 0, (1e-3, 0.9, 0.999, 1e-8, 1e-5))
-        np.savez(os.path.join(out_dir, f"s{rank}.npz"), U=comp.U, V=comp.V, vV=comp.vV, losses=losses.numpy(),
-                 bounds=np.array([comp.u_lo, comp.u_hi, comp.v_lo, comp.v_hi]))
+        out = {}
+        for tag, pipelined in (("", True), ("_strict", False)):
+            comp = OracleShardCompute(U0, V0, rank, world, 1e-3, 1e-5)
+            losses = mdist.train_steps_sharded(comp, stream, B, 0, (1e-3, 0.9, 0.999, 1e-8, 1e-5), pipelined=pipelined)
+            out.update({"U" + tag: comp.U, "V" + tag: comp.V, "vV" + tag: comp.vV, "losses" + tag: losses.numpy(),
+                        "ahead" + tag: np.array(getattr(comp, "ahead_calls", 0))})
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), bounds=np.array([comp.u_lo, comp.u_hi, comp.v_lo, comp.v_hi]),
+                 collide=mdist.batch_collisions(stream.numpy(), B), **out)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_row_sharded_run_equals_single_process_same_batch(tmp_path, orc):
+@pytest.mark.parametrize("case", ["dense", "sparse"])
+def test_two_rank_row_sharded_run_equals_single_process_same_batch(tmp_path, orc, case):
     """World 2 over gloo: each rank holds half the rows of U, V, m, v; the batch stays B (NOT B*world); one int32
     all-reduce of the batch's rows per step.  The concatenated shards must equal the single-process oracle run with
-    the SAME batch size, and both ranks must report the same step losses."""
+    the SAME batch size, and both ranks must report the same step losses.  Both chains run: the pipelined one (the
+    all-reduce of batch k+1 in flight under step k wherever the two batches share no row, its rows rolled forward over
+    step k) must equal the strict pack -> all-reduce -> step chain BIT FOR BIT."""
     from oracle import oracle as O
     world = 2
-    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
     r0, r1 = (dict(np.load(tmp_path / f"s{r}.npz")) for r in range(world))
     np.testing.assert_array_equal(r0["losses"], r1["losses"])
-    assert r0["bounds"].tolist() == [0, 20, 0, 15] and r1["bounds"].tolist() == [20, 41, 15, 30]
-    rng = np.random.default_rng(8)
-    n, m, d, B, N = 41, 30, 8, 16, 16 * 9 + 5
-    U0 = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
-    V0 = (rng.standard_normal((m, d)) / np.sqrt(d)).astype(np.float32)
-    u, i = rng.integers(0, n, N), rng.integers(0, m, N)
-    j = (i + 1 + rng.integers(0, m - 1, N)) % m
-    z = rng.integers(0, 2, N).astype(np.float64)
+    n, m, d, B, N, U0, V0, u, i, j, z = _shard_inputs(case)
+    assert r0["bounds"].tolist() == [0, n // 2, 0, m // 2] and r1["bounds"].tolist() == [n // 2, n, m // 2, m]
+    nsteps = (N + B - 1) // B
+    free = int((~r0["collide"][:nsteps - 1]).sum())
+    assert int(r0["ahead"]) == free and int(r0["ahead_strict"]) == 0
+    assert free == 0 if case == "dense" else free > nsteps // 2
+    for key in ("U", "V", "vV", "losses"):
+        for r in (r0, r1):
+            np.testing.assert_array_equal(r[key], r[key + "_strict"], err_msg=key)
     ref = O.new_state(U0, V0)
     ref_loss = orc.train_steps(ref, u, i, j, z, B, 0, lr=1e-3, wd=1e-5)
     np.testing.assert_allclose(r0["losses"], ref_loss, rtol=2e-6, atol=1e-7)

@@ -1173,6 +1173,47 @@ def test_row_sharded_rehearsal_is_bit_identical_to_the_streaming_step(dev, world
             assert torch.equal(opt.state[prm][key], opt2.state[prm2][key]), key
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_pipelined_shard_exchange_equals_the_strict_chain(dev, world):
+    """the exchange of batch k+1 runs under step k wherever the two batches share no row — its rows
+    are packed AHEAD of step k, rolled forward over it with the step kernel's own dense update (zero sparse gradient).
+    At a shape where both kinds of pair occur (about a quarter of the consecutive batches share no row) the pipelined
+    chain (default), the strict chain (MFCD_TUNE_SHARD_PIPELINE 0) and the single-GPU streaming step agree BIT FOR
+    BIT; the device collision marks equal the host form the Python-level loop uses."""
+    from mfcd import _lib, dist as mdist, engine
+    n, m, d, B, N = 20000, 15000, 16, 64, 64 * 60 + 9
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=world + 40)
+    st = _records(u, i, j, z, n, m, dev)
+    nsteps = (N + B - 1) // B
+    flags = torch.full((nsteps,), 7, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().mfcd_shard_collisions(_lib.ptr(st.dev), N, B, _lib.ptr(flags), _lib.stream_ptr(dev)))
+    want = mdist.batch_collisions(st.dev.cpu().numpy(), B)
+    assert np.array_equal(flags.cpu().numpy().astype(bool), want) and not want[-1]
+    free = int((~want[:-1]).sum())
+    assert 5 <= free <= nsteps - 6, free                       # both kinds of pair are exercised
+    engine.set_train_path("streaming")
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        ref_loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).clone()
+    finally:
+        engine.set_train_path("auto")
+    runs = {}
+    for chain in (1, 0):
+        engine.set_tuning(shard_pipeline=chain)
+        try:
+            mk, ok = _model_from(U0, V0, dev, 1e-3, 1e-5)
+            loss = mdist.NativeShard(engine.AdamBinding(mk, ok), simulate_world=world).train_steps(st.dev, B).clone()
+        finally:
+            engine.set_tuning(shard_pipeline=1)
+        runs[chain] = (mk, ok, loss)
+    for chain, (mk, ok, loss) in runs.items():
+        assert torch.equal(loss, ref_loss), chain
+        assert torch.equal(mk.U.data, model.U.data) and torch.equal(mk.V.data, model.V.data), chain
+        for prm, prm2 in ((model.U, mk.U), (model.V, mk.V)):
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(opt.state[prm][key], ok.state[prm2][key]), (chain, key)
+
+
 def test_row_sharded_halves_over_a_one_rank_rccl_group(dev):
     """The split form (pack -> torch.distributed all_reduce of the int32 view -> apply) and the native loop over an
     RCCL communicator, each on a one-rank group: same bits as the streaming step."""
@@ -1212,6 +1253,36 @@ def test_row_sharded_halves_over_a_one_rank_rccl_group(dev):
         nat.close()
         assert torch.equal(loss3, ref_loss)
         assert torch.equal(m3.U.data, model.U.data) and torch.equal(m3.V.data, model.V.data)
+        # the pipelined exchange over a real communicator (side stream, two buffers, events): a shape where most
+        # consecutive batches share no row, both chains of the native loop and both of the Python-level loop
+        n, m, d, N = 30000, 30000, 32, 64 * 50 + 3
+        U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=22)
+        st = _records(u, i, j, z, n, m, dev)
+        assert (~mdist.batch_collisions(st.dev.cpu().numpy(), B)[:-1]).sum() > 10
+        engine.set_train_path("streaming")
+        try:
+            model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+            ref_loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).clone()
+        finally:
+            engine.set_train_path("auto")
+        for chain in (1, 0):
+            engine.set_tuning(shard_pipeline=chain)
+            try:
+                m4, o4 = _model_from(U0, V0, dev, 1e-3, 1e-5)
+                nat = mdist.NativeShard(engine.AdamBinding(m4, o4))
+                loss4 = nat.train_steps(st.dev, B).clone()
+                nat.gather()
+                nat.close()
+            finally:
+                engine.set_tuning(shard_pipeline=1)
+            assert torch.equal(loss4, ref_loss), chain
+            assert torch.equal(m4.U.data, model.U.data) and torch.equal(m4.V.data, model.V.data), chain
+            m5, o5 = _model_from(U0, V0, dev, 1e-3, 1e-5)
+            b5 = engine.AdamBinding(m5, o5)
+            shard = mdist.RowShard(b5, 0, 1)
+            mdist.train_steps_sharded(mdist.HipShardCompute(shard), st.dev, B, 0, b5.hyper(), pipelined=bool(chain))
+            shard.gather()
+            assert torch.equal(m5.U.data, model.U.data) and torch.equal(m5.V.data, model.V.data), chain
     finally:
         if created:
             dist.destroy_process_group()
