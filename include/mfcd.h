@@ -427,6 +427,16 @@ int mfcd_generate_labels(const int32_t *triplets, int64_t T, const float *X, int
 int mfcd_spearman_max_columns(void);
 int mfcd_spearman_rows(const float *A, int64_t lda, const float *X, int64_t ldx, int rows, int m,
                        double *rho, void *stream);
+/*
+ * The same for rows of ANY length (BASELINE configs[3]: m = 65536 items do not fit a workgroup's LDS): blocks of rows
+ * are sorted in global memory by one device-wide segmented radix sort of (key, column) pairs per matrix, then one
+ * workgroup per row forms the run-averaged ranks and the exact integer sums as above (bit-identical to
+ * mfcd_spearman_rows where both apply).  workspace: mfcd_spearman_long_workspace_bytes(rows, m) bytes (28 bytes per
+ * element of a row block of about 256 MiB; 0 = sizes out of range).
+ */
+size_t mfcd_spearman_long_workspace_bytes(int rows, int m);
+int mfcd_spearman_rows_long(const float *A, int64_t lda, const float *X, int64_t ldx, int rows, int m, double *rho,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Triplet sampling on the device (replaces the per-attempt rejection loops of generation_data.py:16-224

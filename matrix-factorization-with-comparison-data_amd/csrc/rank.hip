@@ -17,10 +17,18 @@
 //     column's A rank, and the three sums of the correlation are accumulated as EXACT 64-bit integers of the doubled,
 //     centred ranks (|2 rank - (m+1)| <= m, sums <= 4 m^3 < 2^46), reduced in fixed order; rho is formed in f64.
 // The result is therefore independent of thread scheduling and equals scipy's float64 computation to rounding.
-// LDS: 8 m bytes (156 KiB at m = 20000).  Rows longer than 20448 are not handled here (host: torch ops).
+// LDS: 8 m bytes (156 KiB at m = 20000).
+// Rows longer than 20448 columns (BASELINE configs[3]: 65536 items) do not fit a workgroup's LDS: mfcd_spearman_rows_long
+// sorts a block of rows at a time in global memory — one device-wide SEGMENTED radix sort of (key, column) pairs per
+// matrix (a segment = a row) — and a workgroup per row then walks its sorted row exactly as above, with the sorted
+// arrays and A's ranks by column in a caller-provided workspace (L2-resident: 512 KiB per row at m = 65536) instead of
+// LDS.  Same keys, same run rule, same exact integer sums: the two paths agree bit for bit where both apply.
 #include <cstring>
 
 #include <rocprim/block/block_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 
@@ -215,6 +223,105 @@ int launch_radix(const float *A, int64_t lda, const float *X, int64_t ldx, int r
     return 0;
 }
 
+// ---- rows of any length: sorted in global memory --------------------------------------------------------------
+struct RowOffset {
+    int m;
+    __host__ __device__ unsigned operator()(unsigned r) const { return r * (unsigned)m; }
+};
+
+__global__ __launch_bounds__(256) void rank_keys_kernel(const float *__restrict__ M, int64_t ld, int rows, int m,
+                                                        unsigned *__restrict__ keys, unsigned *__restrict__ cols,
+                                                        int *__restrict__ nan_rows)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)rows * m) return;
+    const int r = (int)(e / m), c = (int)(e - (int64_t)r * m);
+    const float f = M[(int64_t)r * ld + c];
+    if (f != f) nan_rows[r] = 1;
+    keys[e] = sortable_key(f);
+    cols[e] = (unsigned)c;
+}
+
+// one workgroup per row: pass 0 walks A's sorted row (ranks by column -> ra2, sum of squares), pass 1 walks X's
+__global__ __launch_bounds__(kRankThreads) void spearman_sorted_rows_kernel(const unsigned *__restrict__ keyA,
+                                                                            const unsigned *__restrict__ colA,
+                                                                            const unsigned *__restrict__ keyX,
+                                                                            const unsigned *__restrict__ colX, int m,
+                                                                            unsigned *__restrict__ ra2_all,
+                                                                            const int *__restrict__ nan_rows,
+                                                                            double *__restrict__ rho)
+{
+    __shared__ long long red[kRankThreads / 64];
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const long long centre = (long long)m + 1;
+    unsigned *ra2 = ra2_all + r * m;
+    long long saa = 0, sxx = 0, sxy = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const unsigned *key = (pass == 0 ? keyA : keyX) + r * m, *idx = (pass == 0 ? colA : colX) + r * m;
+        long long s_own = 0, s_xy = 0;
+        for (int p = tid; p < m; p += kRankThreads) {
+            const unsigned kp = key[p];
+            if (p > 0 && key[p - 1] == kp) continue;            // not the first element of its run
+            int e = p;
+            while (e + 1 < m && key[e + 1] == kp) ++e;
+            const long long c2 = (long long)(p + e + 2) - centre;
+            s_own += c2 * c2 * (long long)(e - p + 1);
+            if (pass == 0) {
+                for (int q = p; q <= e; ++q) ra2[idx[q]] = (unsigned)(p + e + 2);
+            } else {
+                for (int q = p; q <= e; ++q) s_xy += c2 * ((long long)ra2[idx[q]] - centre);
+            }
+        }
+        if (pass == 0) saa = s_own;
+        else { sxx = s_own; sxy = s_xy; }
+        __threadfence_block();
+        __syncthreads();                                         // ra2 of this row is complete before X's pass reads it
+    }
+    const long long Saa = block_sum_i64(saa, red), Sxx = block_sum_i64(sxx, red), Sxy = block_sum_i64(sxy, red);
+    if (tid == 0)
+        rho[r] = nan_rows[r] ? __longlong_as_double(0x7ff8000000000000ll) : (double)Sxy / (sqrt((double)Saa) * sqrt((double)Sxx));
+}
+
+struct LongCarve {
+    unsigned *k_in, *c_in, *kA, *cA, *kX, *cX, *ra2;
+    int *nan_rows;
+    void *temp;
+    size_t temp_bytes, total;
+};
+
+int long_carve(int block_rows, int m, void *base, LongCarve &c)
+{
+    const size_t E = (size_t)block_rows * m;
+    size_t tb = 0;
+    using off_it = rocprim::transform_iterator<rocprim::counting_iterator<unsigned>, RowOffset>;
+    off_it begin(rocprim::counting_iterator<unsigned>(0), RowOffset{m}), end(rocprim::counting_iterator<unsigned>(1), RowOffset{m});
+    if (rocprim::segmented_radix_sort_pairs(nullptr, tb, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
+                                            (unsigned *)nullptr, (unsigned)E, (unsigned)block_rows, begin, end, 0, 32,
+                                            (hipStream_t)0) != hipSuccess)
+        return MFCD_EINVAL;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *q = p ? p + off : nullptr; off += (bytes + 255) & ~(size_t)255; return (void *)q; };
+    c.k_in = (unsigned *)take(E * 4); c.c_in = (unsigned *)take(E * 4);
+    c.kA = (unsigned *)take(E * 4); c.cA = (unsigned *)take(E * 4);
+    c.kX = (unsigned *)take(E * 4); c.cX = (unsigned *)take(E * 4);
+    c.ra2 = (unsigned *)take(E * 4);
+    c.nan_rows = (int *)take((size_t)block_rows * 4);
+    c.temp_bytes = tb;
+    c.temp = take(tb);
+    c.total = off;
+    return 0;
+}
+
+// rows sorted per call of the long path: bounds the workspace (28 bytes per element) near 256 MiB
+int long_block_rows(int rows, int m)
+{
+    int64_t b = ((int64_t)256 << 20) / ((int64_t)28 * m);
+    if (b < 1) b = 1;
+    return (int)(b < rows ? b : rows);
+}
+
 int g_rank_sort = 1;   // 1 = radix (default), 0 = bitonic network (mfcd_set_tuning(MFCD_TUNE_RANK_SORT))
 
 }  // namespace
@@ -253,5 +360,46 @@ extern "C" int mfcd_spearman_rows(const float *A, int64_t lda, const float *X, i
     hipLaunchKernelGGL(spearman_rows_kernel, dim3((unsigned)rows), dim3(kRankThreads), lds, (hipStream_t)stream, A, lda, X,
                        ldx, m, P, rho);
     MFCD_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" size_t mfcd_spearman_long_workspace_bytes(int rows, int m)
+{
+    if (rows <= 0 || m <= 0 || (int64_t)long_block_rows(rows, m) * m >= (int64_t)0x7fffffff) return 0;
+    LongCarve c;
+    return long_carve(long_block_rows(rows, m), m, nullptr, c) == 0 ? c.total : 0;
+}
+
+extern "C" int mfcd_spearman_rows_long(const float *A, int64_t lda, const float *X, int64_t ldx, int rows, int m,
+                                       double *rho, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!A || !X || !rho || rows < 0 || m <= 0 || lda < m || ldx < m) return MFCD_EINVAL;
+    if (rows == 0) return 0;
+    if (!workspace) return MFCD_EINVAL;
+    const int R = long_block_rows(rows, m);
+    if ((int64_t)R * m >= (int64_t)0x7fffffff) return MFCD_EINVAL;
+    LongCarve c;
+    if (long_carve(R, m, workspace, c) != 0) return MFCD_EINVAL;
+    if (workspace_bytes < c.total) return MFCD_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    using off_it = rocprim::transform_iterator<rocprim::counting_iterator<unsigned>, RowOffset>;
+    off_it begin(rocprim::counting_iterator<unsigned>(0), RowOffset{m}), end(rocprim::counting_iterator<unsigned>(1), RowOffset{m});
+    for (int r0 = 0; r0 < rows; r0 += R) {
+        const int nr = rows - r0 < R ? rows - r0 : R;
+        const int64_t E = (int64_t)nr * m;
+        MFCD_HIP_TRY(hipMemsetAsync(c.nan_rows, 0, (size_t)nr * 4, st));
+        for (int pass = 0; pass < 2; ++pass) {
+            const float *M = pass == 0 ? A + (int64_t)r0 * lda : X + (int64_t)r0 * ldx;
+            hipLaunchKernelGGL(rank_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, M, pass == 0 ? lda : ldx,
+                               nr, m, c.k_in, c.c_in, c.nan_rows);
+            size_t tb = c.temp_bytes;
+            MFCD_HIP_TRY(rocprim::segmented_radix_sort_pairs(c.temp, tb, c.k_in, pass == 0 ? c.kA : c.kX, c.c_in,
+                                                             pass == 0 ? c.cA : c.cX, (unsigned)E, (unsigned)nr, begin, end,
+                                                             0, 32, st));
+        }
+        hipLaunchKernelGGL(spearman_sorted_rows_kernel, dim3((unsigned)nr), dim3(kRankThreads), 0, st, c.kA, c.cA, c.kX, c.cX,
+                           m, c.ra2, c.nan_rows, rho + r0);
+        MFCD_HIP_TRY(hipGetLastError());
+    }
     return 0;
 }

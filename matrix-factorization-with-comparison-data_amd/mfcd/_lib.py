@@ -66,6 +66,8 @@ SIGNATURES = {
     "mfcd_sample_triplets": (_i32, [_vp, _vp, _i64, _i64, _i64, ctypes.c_uint64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_spearman_max_columns": (_i32, []),
     "mfcd_spearman_rows": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "mfcd_spearman_long_workspace_bytes": (_sz, [_i32, _i32]),
+    "mfcd_spearman_rows_long": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
 }
 
 TUNE_KEYS = {"resident_q": 1, "resident_wpc": 2, "resident_lookahead": 3, "resident_lds_pad": 4,

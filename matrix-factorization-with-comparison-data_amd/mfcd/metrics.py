@@ -125,8 +125,9 @@ def _rank_rows(M):
 
 
 def spearman_rows_sorted(A, X):
-    """Per-row Spearman rho for rows LONGER than the LDS kernel holds (m > mfcd_spearman_max_columns(), e.g. BASELINE
-    configs[3]'s 65536 items): device sort, run-averaged ranks, f64 sums.  NaN in either row -> NaN (scipy propagates)."""
+    """Per-row Spearman rho by plain torch ops (device sort, run-averaged ranks, f64 sums; NaN in either row -> NaN).
+    NOT on the product path since round 3 (rows of any length go through the HIP rank kernels): kept as an independent
+    formulation the GPU tests hold the kernels against beside scipy."""
     ra, rx = _rank_rows(A), _rank_rows(X)
     ra = ra - ra.mean(1, keepdim=True)
     rx = rx - rx.mean(1, keepdim=True)
@@ -135,15 +136,33 @@ def spearman_rows_sorted(A, X):
     return torch.where(bad, torch.full_like(rho, float("nan")), rho)
 
 
-def spearman_rows_any(A, X, row_block=1024):
-    """Per-row Spearman rho for any row length: the HIP rank kernel up to its column limit, the device sort path above it
-    (in row blocks: its temporaries are ~40 bytes per element)."""
+def spearman_rows_any(A, X):
+    """Per-row Spearman rho for any row length: the LDS rank kernel up to its column limit, the global-memory form of the
+    same kernel (mfcd_spearman_rows_long: segmented device sort of row blocks) above it."""
     if A.shape[1] <= _lib.load().mfcd_spearman_max_columns():
         return spearman_rows(A, X)
-    out = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
-    for r0 in range(0, A.shape[0], row_block):
-        out[r0:r0 + row_block] = spearman_rows_sorted(A[r0:r0 + row_block], X[r0:r0 + row_block])
-    return out
+    return spearman_rows_long(A, X)
+
+
+def spearman_rows_long(A, X):
+    """include/mfcd.h mfcd_spearman_rows_long: rows of any length (BASELINE configs[3]: 65536 items), f64 [rows]."""
+    L = _lib.load()
+    rows, m = A.shape
+    if X.shape != A.shape or A.dtype != torch.float32 or X.dtype != torch.float32 or not A.is_cuda or not X.is_cuda:
+        raise _lib.MfcdError("spearman_rows_long needs two float32 GPU matrices of the same shape")
+    if A.stride(1) != 1 or X.stride(1) != 1:
+        A, X = A.contiguous(), X.contiguous()
+    rho = torch.empty(rows, dtype=torch.float64, device=A.device)
+    if rows == 0:
+        return rho
+    need = L.mfcd_spearman_long_workspace_bytes(rows, m)
+    if need == 0:
+        raise _lib.MfcdError(f"rows of {m} columns are beyond the rank kernels")
+    ws = _workspace(need, A.device)
+    _lib.check(L.mfcd_spearman_rows_long(A.data_ptr(), A.stride(0) if rows > 1 else m, X.data_ptr(),
+                                         X.stride(0) if rows > 1 else m, rows, m, _lib.ptr(rho), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr(A.device)))
+    return rho
 
 
 def spearman_rows(A, X):

@@ -1704,9 +1704,10 @@ def test_x_spectrum_cache_is_tied_to_the_matrix_not_to_its_address(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,m", [(6, 20449), (5, 32768), (4, 65536)])    # 65536 = BASELINE configs[3]'s item count
 def test_spearman_rows_longer_than_the_lds_kernel_match_scipy(dev, rows, m):
-    """Rows longer than mfcd_spearman_max_columns() (20448) take the device sort path of mfcd.metrics (torch.sort +
-    run-averaged ranks, f64 sums).  Same checks as the kernel's test: scipy.stats.spearmanr row by row, ties in one and
-    in both operands, -0.0 / +0.0, a constant row (NaN), a NaN entry (NaN, as scipy)."""
+    """Rows longer than mfcd_spearman_max_columns() (20448) take mfcd_spearman_rows_long (segmented device sort of row
+    blocks in global memory, then the LDS kernel's own rank / exact-sum pass per row).  Same checks as the kernel's test:
+    scipy.stats.spearmanr row by row, ties in one and in both operands, -0.0 / +0.0, a constant row (NaN); the plain-torch
+    formulation (metrics.spearman_rows_sorted, off the product path) agrees too, and two calls are bit-equal."""
     from scipy.stats import spearmanr
     from mfcd import metrics
     rng = np.random.default_rng(m)
@@ -1717,13 +1718,33 @@ def test_spearman_rows_longer_than_the_lds_kernel_match_scipy(dev, rows, m):
     A[0, : m // 2] = 0.0
     A[0, 0] = -0.0
     X[3] = 1.25
-    got = metrics.spearman_rows_any(torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev)).cpu().numpy()
+    Ad, Xd = torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev)
+    got = metrics.spearman_rows_any(Ad, Xd).cpu().numpy()
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         want = np.array([spearmanr(A[r], X[r]).correlation for r in range(rows)])
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, equal_nan=True)
     assert np.isnan(got[3])
+    assert np.array_equal(got, metrics.spearman_rows_long(Ad, Xd).cpu().numpy(), equal_nan=True)
+    np.testing.assert_allclose(got, metrics.spearman_rows_sorted(Ad, Xd).cpu().numpy(), rtol=0, atol=1e-12, equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,m", [(37, 1000), (9, 20000), (300, 4097)])
+def test_long_row_spearman_path_equals_the_lds_kernel_bit_for_bit(dev, rows, m):
+    """Where both apply (m <= 20448) the global-memory path must return the LDS kernel's value exactly: same keys, same
+    run rule, same exact integer sums — including rows cut into several sort blocks, strided inputs, ties and NaN."""
+    from mfcd import metrics
+    rng = np.random.default_rng(rows + m)
+    A = rng.standard_normal((rows, m + 5)).astype(np.float32)
+    X = np.round(rng.standard_normal((rows, m)) * 3.0).astype(np.float32) / 3.0
+    A[1, 7] = np.nan
+    X[2] = -0.0
+    Ad, Xd = torch.from_numpy(A).to(dev)[:, :m], torch.from_numpy(X).to(dev)
+    a = metrics.spearman_rows(Ad, Xd).cpu().numpy()
+    b = metrics.spearman_rows_long(Ad, Xd).cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True) and np.isnan(a[1]) and np.isnan(a[2]) and np.isfinite(a[0])
 
 
 @pytest.mark.gpu
