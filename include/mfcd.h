@@ -305,6 +305,12 @@ int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, float *mV, flo
                         const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0, int n,
                         int m, int d, double lr, double beta1, double beta2, double eps, double weight_decay,
                         float *loss_per_step, void *workspace, size_t workspace_bytes, void *comm, void *stream);
+/* the same loop over bf16 factor tables (BASELINE configs[2]; moments, wire format and arithmetic stay fp32; equals
+ * mfcd_train_steps_bf16's streaming form with batch_size = B * world) */
+int mfcd_dp_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, float *mV, float *vV,
+                        const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0, int n,
+                        int m, int d, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        float *loss_per_step, void *workspace, size_t workspace_bytes, void *comm, void *stream);
 
 /*
  * Row-sharded training: STRONG scaling with the reference's batch size (structure.py:668, B = 64), results equal to

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void coeff_kernel(const float *__restrict__ U,
 // Data-parallel exchange slot of one rank for one step: B interleaved pairs {g_t, BCE term_t}; one wave per slot entry.
 // Entries past the rank's (possibly short or empty) shard are written as {0, 0} so that the gathered buffer of a
 // step is fully defined.
-__global__ __launch_bounds__(256) void dp_coeff_kernel(const float *__restrict__ U, const float *__restrict__ V,
+template <typename TP>
+__global__ __launch_bounds__(256) void dp_coeff_kernel(const TP *__restrict__ U, const TP *__restrict__ V,
                                                        const mfcd_sample *__restrict__ shard, int myB, int B, int d,
                                                        float inv_batch, float2 *__restrict__ slot)
 {
@@ -1251,11 +1252,13 @@ extern "C" size_t mfcd_dp_workspace_bytes(int64_t N, int B, int world, int n, in
            align256(sizeof(float2) * (size_t)(nsteps > 0 ? nsteps : 1) * (size_t)Bg);
 }
 
-extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
-                                   const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0,
-                                   int n, int m, int d, double lr, double beta1, double beta2, double eps,
-                                   double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
-                                   void *comm, void *stream)
+namespace {
+// fp32 or bf16 factor tables (BASELINE configs[2]); the moments, the coefficients on the wire and the arithmetic are fp32
+template <typename TP>
+int run_dp_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *samples, int64_t N,
+                       int B, int rank, int world, int64_t step0, int n, int m, int d, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, float *loss_per_step, void *workspace,
+                       size_t workspace_bytes, void *comm, void *stream)
 {
     if (int rc = check_common(U, V, n, m, d)) return rc;
     if (!mU || !vU || !mV || !vV || N < 0 || B <= 0 || world < 1 || rank < 0 || rank >= world || step0 < 0)
@@ -1271,9 +1274,9 @@ extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, flo
     hipStream_t st = (hipStream_t)stream;
     const int64_t Bg = (int64_t)B * world, nsteps = (N + Bg - 1) / Bg;
     char *ws = (char *)workspace + kStatusBytes;
-    float *Ualt = (float *)ws;
+    TP *Ualt = (TP *)ws;
     ws += align256(sizeof(float) * (size_t)n * d);
-    float *Valt = (float *)ws;
+    TP *Valt = (TP *)ws;
     ws += align256(sizeof(float) * (size_t)m * d);
     float2 *xbuf = (float2 *)ws;   // [nsteps][world][B] pairs = global sample order inside a step
     const void *ptrs[] = {U, V, mU, vU, mV, vV, Ualt, Valt};
@@ -1282,7 +1285,7 @@ extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, flo
         const int64_t lo = k * Bg, hi = (lo + Bg < N) ? lo + Bg : N;
         const int nglob = (int)(hi - lo);          // divisor of the mean (structure.py:849): the GLOBAL batch
         const bool even = (k & 1) == 0;
-        const float *Uc = even ? U : Ualt, *Vc = even ? V : Valt;
+        const TP *Uc = even ? U : Ualt, *Vc = even ? V : Valt;
         float2 *xk = xbuf + (size_t)k * Bg;
         // ranks this process computes: its own; or, without a communicator, every rank in turn (replicas are
         // bit-identical, so this reproduces the gathered buffer exactly: single-process rehearsal of any world size)
@@ -1290,7 +1293,7 @@ extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, flo
         for (int r = r0; r < r1; ++r) {
             const int64_t mylo = (lo + (int64_t)r * B < hi) ? lo + (int64_t)r * B : hi;
             const int64_t myhi = (mylo + B < hi) ? mylo + B : hi;
-            hipLaunchKernelGGL(dp_coeff_kernel, dim3((B + 3) / 4), dim3(256), 0, st, Uc, Vc, samples + mylo,
+            hipLaunchKernelGGL(dp_coeff_kernel<TP>, dim3((B + 3) / 4), dim3(256), 0, st, Uc, Vc, samples + mylo,
                                (int)(myhi - mylo), B, d, 1.0f / (float)nglob, xk + (size_t)r * B);
         }
         if (comm) {   // also on a one-rank communicator: the call path is the same at every world size
@@ -1298,19 +1301,41 @@ extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, flo
                 return MFCD_ERCCL;
         }
         const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step0 + k + 1);
-        dispatch_step<0, float>(pl, st, Uc, Vc, even ? Ualt : U, even ? Valt : V, mU, vU, mV, vV, samples + lo,
+        dispatch_step<0, TP>(pl, st, Uc, Vc, even ? Ualt : U, even ? Valt : V, mU, vU, mV, vV, samples + lo,
                                 (const float *)xk, nglob, 0.0f, n, m, d, ac, nullptr, nullptr, nullptr, 2);
     }
     MFCD_HIP_TRY(hipGetLastError());
     if (nsteps & 1) {
-        MFCD_HIP_TRY(hipMemcpyAsync(U, Ualt, sizeof(float) * (size_t)n * d, hipMemcpyDeviceToDevice, st));
-        MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(float) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
+        MFCD_HIP_TRY(hipMemcpyAsync(U, Ualt, sizeof(TP) * (size_t)n * d, hipMemcpyDeviceToDevice, st));
+        MFCD_HIP_TRY(hipMemcpyAsync(V, Valt, sizeof(TP) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
     }
     if (loss_per_step) {
         hipLaunchKernelGGL(dp_loss_kernel, dim3((unsigned)nsteps), dim3(64), 0, st, xbuf, N, (int)Bg, loss_per_step);
         MFCD_HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+}  // namespace
+
+extern "C" int mfcd_dp_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                                   const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0,
+                                   int n, int m, int d, double lr, double beta1, double beta2, double eps,
+                                   double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
+                                   void *comm, void *stream)
+{
+    return run_dp_train_steps<float>(U, V, mU, vU, mV, vV, samples, N, B, rank, world, step0, n, m, d, lr, beta1, beta2,
+                                     eps, weight_decay, loss_per_step, workspace, workspace_bytes, comm, stream);
+}
+
+extern "C" int mfcd_dp_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, float *mV, float *vV,
+                                        const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0,
+                                        int n, int m, int d, double lr, double beta1, double beta2, double eps,
+                                        double weight_decay, float *loss_per_step, void *workspace,
+                                        size_t workspace_bytes, void *comm, void *stream)
+{
+    return run_dp_train_steps<mfcd_bf16>((mfcd_bf16 *)U, (mfcd_bf16 *)V, mU, vU, mV, vV, samples, N, B, rank, world, step0,
+                                         n, m, d, lr, beta1, beta2, eps, weight_decay, loss_per_step, workspace,
+                                         workspace_bytes, comm, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

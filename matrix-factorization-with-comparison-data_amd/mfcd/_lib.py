@@ -46,6 +46,8 @@ SIGNATURES = {
     "mfcd_dp_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32, _i32]),
     "mfcd_dp_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
                             [_vp, _vp, _sz, _vp, _vp]),
+    "mfcd_dp_train_steps_bf16": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
+                            [_vp, _vp, _sz, _vp, _vp]),
     "mfcd_shard_rows": (_i32, [_i32, _i32, _i32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mfcd_shard_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mfcd_shard_pack": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -103,8 +103,9 @@ class NativeDP:
         self.b = binding
         self.L = _lib.load()
         U, V = binding.model.U.data, binding.model.V.data
-        if U.dtype != torch.float32:
-            raise NotImplementedError("the data-parallel loop takes fp32 factors (bf16 factor storage is single-GPU)")
+        if U.dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError("the data-parallel loop takes fp32 or bf16 factor tables")
+        self.entry = self.L.mfcd_dp_train_steps if U.dtype == torch.float32 else self.L.mfcd_dp_train_steps_bf16
         self.n, self.d, self.m, self.dev = U.shape[0], U.shape[1], V.shape[0], U.device
         self.comm = None
         if simulate_world is not None:
@@ -133,7 +134,7 @@ class NativeDP:
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty(int(need), dtype=torch.uint8, device=self.dev)
         lr, b1, b2, eps, wd = self.b.hyper()
-        _lib.check(self.L.mfcd_dp_train_steps(
+        _lib.check(self.entry(
             _lib.ptr(U), _lib.ptr(V), _lib.ptr(mU), _lib.ptr(vU), _lib.ptr(mV), _lib.ptr(vV), _lib.ptr(stream), N,
             batch_local, self.rank, self.world, self.b.step, self.n, self.m, self.d, lr, b1, b2, eps, wd,
             _lib.ptr(loss_out), _lib.ptr(self.ws), self.ws.numel(), self.comm, _lib.stream_ptr(self.dev)))
