@@ -18,6 +18,7 @@ for tag, name in (("prof_driver", "r03_bench_c2_driver_cmd_kernel_stats.csv"), (
 for name in ("bench_c2_default.json", "bench_c2_driver_cmd.json", "bench_c2_driver_cmd_under_rocprof.json",
              "bench_c2_under_rocprof.json", "bench_c3_f32.json", "bench_c3_bf16.json", "bench_c4_single.json",
              "bench_c2_dp_native_one_rank.json", "bench_c2_shard_one_rank.json", "bench_c4_shard_one_rank.json",
+             "bench_c4_shard_one_rank_strict.json", "samplers.txt",
              "uvt_pass_roofline.txt", "metric_functions_c2.txt", "step_period_by_size.txt", "short_call_breakdown.txt",
              "tiny_problem_forms.txt", "resident_pmc_c2.txt", "resident_pmc_c3.txt", "streaming_pmc_C4.txt",
              "streaming_pmc_C5.txt", "resident_common_path.txt", "uvt_pass_vs_load_history.txt",

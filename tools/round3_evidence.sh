@@ -13,6 +13,9 @@ timeout -k 10 300 python bench.py --workload C3 --factor-dtype bf16 --steps 3356
 timeout -k 10 300 python bench.py --workload C4 --steps 2000 --warmup 200 --no-cpu-baseline --no-extras > $E/bench_c4_single.json 2>/dev/null; cut -c1-200 $E/bench_c4_single.json
 timeout -k 10 300 python bench.py --dp-mode native --no-cpu-baseline --steps 2098 --warmup 1049 > $E/bench_c2_dp_native_one_rank.json 2>/dev/null; cut -c1-200 $E/bench_c2_dp_native_one_rank.json
 timeout -k 10 300 python bench.py --dp-mode shard --no-cpu-baseline --steps 2098 --warmup 1049 > $E/bench_c2_shard_one_rank.json 2>/dev/null; cut -c1-200 $E/bench_c2_shard_one_rank.json
+timeout -k 10 300 python bench.py --workload C4 --dp-mode shard --no-cpu-baseline --no-extras --steps 2000 --warmup 200 > $E/bench_c4_shard_one_rank.json 2>/dev/null; cut -c1-200 $E/bench_c4_shard_one_rank.json
+timeout -k 10 300 python bench.py --workload C4 --dp-mode shard --tune shard_pipeline=0 --no-cpu-baseline --no-extras --steps 2000 --warmup 200 > $E/bench_c4_shard_one_rank_strict.json 2>/dev/null; cut -c1-200 $E/bench_c4_shard_one_rank_strict.json
+timeout -k 10 300 python tools/bench_samplers.py > $E/samplers.txt 2>&1; tail -6 $E/samplers.txt
 timeout -k 10 300 python tools/bench_uvt.py > $E/uvt_pass_roofline.txt 2>&1; cat $E/uvt_pass_roofline.txt | cut -c1-240
 timeout -k 10 300 python tools/bench_metrics.py > $E/metric_functions_c2.txt 2>&1; cat $E/metric_functions_c2.txt
 timeout -k 10 400 python tools/bench_metrics_c5.py > $E/metric_functions_c5.txt 2>&1; tail -6 $E/metric_functions_c5.txt
