@@ -577,6 +577,9 @@ def _run(args):
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
+        if args.tune:
+            from mfcd import engine as _eng
+            _eng.set_tuning(**{k: int(v) for k, v in (kv.split("=", 1) for kv in args.tune)})
         out = mdist.bench_data_parallel(cfg, dev, args.steps, args.warmup, args.seed, mode=args.dp_mode or "native")
         dist.destroy_process_group()
         return out, rank == 0

@@ -137,7 +137,7 @@ int mfcd_set_resident_math(int fast);
 #define MFCD_TUNE_UVT_TARGET_WGS 9      /* UV^T pass: workgroups the column split aims for (default 512)       */
 #define MFCD_TUNE_UVT_SPLIT 11          /* UV^T pass, d in {32, 64, 128}: 1 (default) = bf16x3 split product on the bf16 matrix pipe, 0 = fp32 MFMA */
 #define MFCD_TUNE_RANK_SORT 12          /* Spearman kernel's sort: 1 (default) = block radix sort, 0 = bitonic network in LDS */
-#define MFCD_TUNE_SHARD_PIPELINE 13     /* row-sharded native loop: 1 (default) = exchange of batch k+1 under step k, 0 = strict chain */
+#define MFCD_TUNE_SHARD_PIPELINE 13     /* row-sharded native loop: 1 (default) = exchange of batch k+1 under step k when world > 1, 2 = always, 0 = strict chain */
 #define MFCD_TUNE_UVT_MIN_STAGES 10     /* UV^T pass: column stages a workgroup sweeps at least (default 8)    */
 int mfcd_set_tuning(int key, int64_t value);
 
@@ -336,10 +336,11 @@ int mfcd_dp_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, flo
  *                                        run underneath step k.  Only legal when no row of the next batch is named
  *                                        by the current one:
  *   mfcd_shard_collisions                flags[k] (uint8, device) = 1 when batch k+1 shares a row with batch k.
- * mfcd_shard_train_steps takes the pipelined chain by default (MFCD_TUNE_SHARD_PIPELINE 0 restores pack -> all-reduce
- * -> step on one stream): collectives on a side stream, two exchange buffers, strict chain only across colliding
- * pairs; it reads the collision flags on the host once per call (its one host wait).  Results are bit-identical in
- * both chains.
+ * mfcd_shard_train_steps takes the pipelined chain by default when world > 1 (MFCD_TUNE_SHARD_PIPELINE 0 restores
+ * pack -> all-reduce -> step on one stream everywhere, 2 pipelines on a one-rank communicator too): the collectives of
+ * free pairs on a side stream, two exchange buffers, the strict chain — on the main stream, no stream hops — across
+ * colliding pairs; it reads the collision flags on the host once per call (its one host wait).  Results are
+ * bit-identical in both chains.
  * xbuf / workspace: mfcd_shard_workspace_bytes(N, B, d) bytes (the buffers come first, 3*B*d floats each).
  * u_lo..v_hi are GLOBAL row bounds of the shard; batch records name global rows.
  */

@@ -326,6 +326,60 @@ void resident_train_kernel(ResidentArgs a)
 #ifdef MFCD_RES_STAMPS
         { const u64 t = RS_NOW(); rs_hit[0] += t - rs_mark; rs_mark = t; }
 #endif
+#if defined(MFCD_RES_STAGGER) && MFCD_RES_STAGGER > 0
+        // EXPERIMENT (make exp EXPFLAGS=-DMFCD_RES_STAGGER=<sleep units>): after a failed first look two sets of poll
+        // loads stay in flight half a round trip apart, so that the memory is sampled twice per round trip
+        {
+            u64 ga[3][S], gb[3][S];
+            auto issue = [&](u64 (&g)[3][S]) MFCD_LAMBDA_INLINE {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (own[r]) continue;
+#pragma unroll
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const int c = lane + 64 * s2;
+                        if (c < D) g[r][s2] = load_granule(slot + (int64_t)r * D + c);
+                    }
+                }
+            };
+            auto check = [&](const u64 (&g)[3][S]) MFCD_LAMBDA_INLINE -> bool {
+                bool ok = true;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (own[r]) continue;
+#pragma unroll
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const int c = lane + 64 * s2;
+                        if (c < D) {
+                            ok = ok && ((unsigned)(g[r][s2] >> 32) == tag);
+                            row[r][s2] = __uint_as_float((unsigned)g[r][s2]);
+                        }
+                    }
+                }
+                return __all(ok);
+            };
+            issue(ga);
+            if (!check(ga)) {
+#ifdef MFCD_RES_STATS
+                rs_w0 = RS_NOW();
+#endif
+                issue(ga);
+                __builtin_amdgcn_s_sleep(MFCD_RES_STAGGER);
+                issue(gb);
+                while (true) {
+                    RS_ADD(5, 1);
+                    if (poll_failed(spins, limit)) {
+                        give_up(step, pos, (own0 ? 1 : 0) | (own1 ? 2 : 0) | (own2 ? 4 : 0));
+                        return false;
+                    }
+                    if (check(ga)) break;
+                    issue(ga);
+                    if (check(gb)) break;
+                    issue(gb);
+                }
+            }
+        }
+#else
         while (true) {
             bool ok = true;
 #pragma unroll
@@ -351,6 +405,7 @@ void resident_train_kernel(ResidentArgs a)
                 return false;
             }
         }
+#endif
 #ifdef MFCD_RES_STATS
         if (spins) RS_ADD(2, RS_NOW() - rs_w0);
         else RS_ADD(4, 1ull << 40);

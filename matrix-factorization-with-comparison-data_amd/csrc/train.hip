@@ -697,7 +697,7 @@ extern "C" int mfcd_set_tuning(int key, int64_t value)
             t.short_call_steps = (int)value;
             return 0;
         case MFCD_TUNE_SHARD_PIPELINE:
-            if (value != 0 && value != 1) return MFCD_EINVAL;
+            if (value < 0 || value > 2) return MFCD_EINVAL;
             t.shard_pipeline = (int)value;
             return 0;
         default: return MFCD_EINVAL;
@@ -1611,7 +1611,11 @@ extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, 
         return 0;
     };
 
-    if (!mfcd_detail::g_tune.shard_pipeline || nsteps < 2) {
+    // 1 (default): pipelined where there is a collective to hide (world > 1) and in the comm-less rehearsal; a one-rank
+    // communicator takes the strict chain (measured, C4 on a one-rank group: the two stream hops of a pipelined step cost
+    // 10 us more than they hide when the collective is a local copy); 2 forces the pipelined chain (tests, timing)
+    const int pipe = mfcd_detail::g_tune.shard_pipeline;
+    if (pipe == 0 || nsteps < 2 || (pipe == 1 && comm && world == 1)) {
         // the strict chain: pack -> all-reduce -> step, one stream
         for (int64_t k = 0; k < nsteps; ++k) {
             if (int rc = pack_now(k, xbufs[0])) return rc;
@@ -1653,20 +1657,32 @@ extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, 
         auto wait_reduced = [&](int b) {
             if (comm && !rc && hipStreamWaitEvent(st, reduced[b], 0) != hipSuccess) fail(MFCD_EINVAL);
         };
+        // a collective on the main stream itself: no overlap wanted, so no stream hops (the first batch, and every
+        // batch that shares a row with the one before it: the strict chain, at the strict chain's cost).  Never concurrent
+        // with a side-stream collective on the same communicator: `st` has met every earlier one by then, and the next
+        // one on the side stream waits for an event recorded on `st` after this call.
+        bool on_side[2] = {false, false};
+        auto reduce_inline = [&](int b) {
+            on_side[b] = false;
+            if (!comm || rc) return;
+            if (R->AllReduce(xbufs[b], xbufs[b], (size_t)3 * B * d, ncclUint32, ncclSum, (ncclComm_t)comm, st) != ncclSuccess)
+                fail(MFCD_ERCCL);
+        };
         if (!rc) fail(pack_now(0, xbufs[0]));
-        reduce_async(0);
+        reduce_inline(0);
         for (int64_t k = 0; k < nsteps && !rc; ++k) {
             const int cur = (int)(k & 1), nxt = cur ^ 1;
             const bool more = k + 1 < nsteps, ahead = more && !collide[(size_t)k];
             if (ahead) {                      // batch k+1 goes on the wire before step k runs
                 fail(pack_ahead(k, xbufs[nxt]));
                 reduce_async(nxt);
+                on_side[nxt] = true;
             }
-            wait_reduced(cur);
+            if (on_side[cur]) wait_reduced(cur);
             if (!rc) fail(apply(k, xbufs[cur]));
             if (more && !ahead) {             // a shared row: batch k+1 is packed from the updated state
                 if (!rc) fail(pack_now(k + 1, xbufs[nxt]));
-                reduce_async(nxt);
+                reduce_inline(nxt);
             }
         }
         if (comm) {

@@ -527,15 +527,19 @@ def _dp_cost_model(cfg, world, sharded):
         # B x B draws from n, no common item among 2B x 2B draws from m) overlap the collective with pack + step
         free = float(np.exp(-cfg["B"] ** 2 / cfg["n"]) * np.exp(-(2 * cfg["B"]) ** 2 / cfg["m"]))
         serial = sum(per_step.values())
-        overlapped = max(per_step["collective_us"], per_step["pack_us"] + per_step["step_us"])
+        hop_us = 7.0          # event record -> wait on the other stream, measured on a one-rank group (profiles/r03_shard_chains_one_rank.txt)
+        # a free step's collective leaves the main stream and comes back (two hops); consecutive free steps form two
+        # interleaved chains apply(k) -> pack_ahead(k+2) -> hop -> collective -> hop -> apply(k+2), each advancing two steps
+        overlapped = max(per_step["pack_us"] + per_step["step_us"],
+                         (per_step["pack_us"] + per_step["step_us"] + 2 * hop_us + per_step["collective_us"]) / 2.0)
         tot = free * overlapped + (1.0 - free) * serial
         return {"per_step_us": per_step, "free_pairs": round(free, 3), "strict_chain_us": round(serial, 1),
-                "overlapped_us": round(overlapped, 1), "sum_us": round(tot, 1),
+                "stream_hop_us": hop_us, "overlapped_us": round(overlapped, 1), "sum_us": round(tot, 1),
                 "predicted_value": round(samples / tot * 1e6, 1),
                 "note": "row-sharded loop with the pipelined exchange: where batch k+1 shares no row with batch k "
                         "(free_pairs of the steps for uniform triplets) its all-reduce runs on a side stream under step "
-                        "k and the step costs max(collective, pack + step); the other pairs keep pack -> collective -> "
-                        "step.  The collective's latency stays the floor: at C2 one GPU's resident form (0.55 us per "
+                        "k (two stream hops per free step; two interleaved chains of free steps) and the other pairs keep "
+                        "pack -> collective -> step on the main stream.  The collective's latency stays the floor: at C2 one GPU's resident form (0.55 us per "
                         "step) is far below it; the form pays off where the state does not fit one GPU's registers "
                         "(C4: 32 us per step on one GPU)"}
     else:

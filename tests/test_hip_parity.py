@@ -1302,7 +1302,7 @@ def test_row_sharded_halves_over_a_one_rank_rccl_group(dev):
             ref_loss = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).clone()
         finally:
             engine.set_train_path("auto")
-        for chain in (1, 0):
+        for chain in (2, 1, 0):              # 2: pipelined on this one-rank communicator too (1 = auto: strict here)
             engine.set_tuning(shard_pipeline=chain)
             try:
                 m4, o4 = _model_from(U0, V0, dev, 1e-3, 1e-5)
