@@ -113,6 +113,37 @@ def offline_traffic(cfg, plan, abytes):
         return None
 
 
+def offline_kernel_stats(cfg, plan, steps_per_launch):
+    """`kernel_only.rocprof_offline`: the dominant kernel's average duration in the newest committed
+    `rocprofv3 --kernel-trace --stats` summary of this command (profiles/r*_bench_c2_driver_cmd_kernel_stats.csv for the
+    driver's 20-step call, r*_bench_c2_kernel_stats.csv for whole epochs), and the roofline fraction at that duration.
+    The live HIP-event pair reads a few microseconds more per launch: it brackets the launch's dispatch and completion
+    signalling as well."""
+    import csv
+    import glob
+    if cfg.get("name", "C2") != "C2" or plan["form_name"] != "resident":
+        return None
+    pat = "r*_bench_c2_driver_cmd_kernel_stats.csv" if steps_per_launch == 20 else \
+        ("r*_bench_c2_kernel_stats.csv" if steps_per_launch >= 1049 else None)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rows = [r for r in csv.DictReader(f) if "resident_train_kernel" in r["Name"]]
+        row = max(rows, key=lambda r: int(r["Calls"]))
+        avg_us = float(row["AverageNs"]) / 1e3
+        launch_steps = 20 if steps_per_launch == 20 else 1049
+        frac = algorithmic_valu_cycles_per_step(cfg) * launch_steps / (avg_us * 1e-6) / 1e9 / (1024 * 2.4)
+        return {"file": os.path.relpath(files[-1], ROOT), "calls": int(row["Calls"]), "avg_us_per_launch": round(avg_us, 2),
+                "steps_per_launch": launch_steps, "frac_at_that_duration": round(frac, 4),
+                "note": "offline profile of the same command on the same kernel build; the launches it averages are mostly "
+                        "the untimed clock ramp's (identical calls)" if steps_per_launch == 20 else
+                        "offline profile of the same command; averages include the shorter event-pair sample launch"}
+    except Exception:
+        return None
+
+
 def roofline_record(cfg, plan, period_us, kernel_us=None, kernel_step_us=None):
     """`roofline` object for the form that actually ran (engine.train_plan), per optimiser step.
     Streaming form: HBM-bound, achieved = algorithmic bytes / time.  Resident / local forms: the state never leaves
@@ -641,6 +672,9 @@ def _run(args):
     out["roofline"]["period_from"] = ("HIP event pairs around the calls of the timed region" if in_region else
                                       "HIP event pair around an identical call issued right after the timed region")
     if kone:
+        off = offline_kernel_stats(cfg, plan, kone["steps_per_launch"])
+        if off:
+            kone["rocprof_offline"] = off
         out["roofline"]["kernel_only"] = kone
     if ramp:
         out["clock_ramp"] = ramp

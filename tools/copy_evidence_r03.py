@@ -14,11 +14,12 @@ def cp(src, dst):
 
 for tag, name in (("prof_driver", "r03_bench_c2_driver_cmd_kernel_stats.csv"), ("prof_bench", "r03_bench_c2_kernel_stats.csv"),
                   ("prof_c3", "r03_bench_c3_kernel_stats.csv"), ("prof_uvt", "r03_uvt_pass_kernel_stats.csv")):
-    cp(newest(f"{E}/{tag}/runc/*_kernel_stats.csv"), name)
+    if glob.glob(f"{E}/{tag}/**/*_kernel_stats.csv", recursive=True):      # a section that was not re-collected keeps its file
+        cp(newest(f"{E}/{tag}/**/*_kernel_stats.csv"), name)
 for name in ("bench_c2_default.json", "bench_c2_driver_cmd.json", "bench_c2_driver_cmd_under_rocprof.json",
              "bench_c2_under_rocprof.json", "bench_c3_f32.json", "bench_c3_bf16.json", "bench_c4_single.json",
              "bench_c2_dp_native_one_rank.json", "bench_c2_shard_one_rank.json", "bench_c4_shard_one_rank.json",
-             "bench_c4_shard_one_rank_strict.json", "samplers.txt",
+             "bench_c4_shard_one_rank_strict.json", "bench_c4_shard_one_rank_pipelined.json", "samplers.txt",
              "uvt_pass_roofline.txt", "metric_functions_c2.txt", "step_period_by_size.txt", "short_call_breakdown.txt",
              "tiny_problem_forms.txt", "resident_pmc_c2.txt", "resident_pmc_c3.txt", "streaming_pmc_C4.txt",
              "streaming_pmc_C5.txt", "resident_common_path.txt", "uvt_pass_vs_load_history.txt",
@@ -27,9 +28,10 @@ for name in ("bench_c2_default.json", "bench_c2_driver_cmd.json", "bench_c2_driv
              "fuzz_parity.txt", "fuzz_bf16.txt", "fuzz_multi_gpu_rehearsal.txt", "fuzz_uvt.txt"):
     if os.path.exists(os.path.join(E, name)):
         cp(os.path.join(E, name), "r03_" + name)
-subprocess.run([sys.executable, "tools/pmc_traffic.py", f"{E}/pmc_c2_fetch", f"{E}/pmc_c2_write", "profiles/r03_pmc_traffic.json"],
-               stdout=subprocess.DEVNULL, check=True)
-print("-> r03_pmc_traffic.json")
+if os.path.isdir(f"{E}/pmc_c2_fetch") and os.path.isdir(f"{E}/pmc_c2_write"):
+    subprocess.run([sys.executable, "tools/pmc_traffic.py", f"{E}/pmc_c2_fetch", f"{E}/pmc_c2_write", "profiles/r03_pmc_traffic.json"],
+                   stdout=subprocess.DEVNULL, check=True)
+    print("-> r03_pmc_traffic.json")
 
 # per-kernel split of one UV^T pass per shape (medians over the passes of the profiled run)
 import re
