@@ -400,20 +400,27 @@ def cpu_baseline(cfg, seed, budget_s=12.0):
                                  "step time beside this port's, same data)"}
 
 
+REAL_STDOUT_FD = None
+
+
 class _StdoutToStderr:
     """Route fd 1 to stderr while the benchmark runs (RCCL prints a version banner on stdout) so that the ONE JSON
     line is the only thing this script ever writes to stdout."""
 
     def __enter__(self):
+        global REAL_STDOUT_FD
         sys.stdout.flush()
         self.saved = os.dup(1)
+        REAL_STDOUT_FD = self.saved      # for a watchdog that has to print the line from inside the run (mfcd/dist.py)
         os.dup2(2, 1)
         return self
 
     def __exit__(self, *exc):
+        global REAL_STDOUT_FD
         sys.stdout.flush()
         os.dup2(self.saved, 1)
         os.close(self.saved)
+        REAL_STDOUT_FD = None
         return False
 
 
