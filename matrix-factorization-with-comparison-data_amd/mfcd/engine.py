@@ -146,15 +146,24 @@ def generate_labels(triplets, X, scale=1.0, K=1, soft=False, seed=0, device=None
     `X` is a dense [n, m] fp32 tensor (moved to the device if needed) or a generation_data.FactoredMatrix, whose n x m
     product is never formed.  Reproducible for a seed; not the reference's CPU generator stream."""
     L = _lib.load()
-    idx = np.ascontiguousarray(np.asarray(triplets, dtype=np.int64).reshape(-1, 3))
-    T = idx.shape[0]
     n, m = X.shape
-    if T and (idx.min() < 0 or idx[:, 0].max() >= n or idx[:, 1:].max() >= m):
-        raise IndexError("triplet index out of range for X")          # as X[u, i] would (structure.py:509)
     if device is None:
         device = X.device if isinstance(X, torch.Tensor) and X.is_cuda else torch.device("cuda")
     device = torch.device(device)
-    trip = torch.from_numpy(idx.astype(np.int32)).to(device)
+    if isinstance(triplets, torch.Tensor) and triplets.is_cuda:
+        # triplets made on the device (mfcd.sampling): they never visit the host
+        trip = triplets.to(device=device, dtype=torch.int32).reshape(-1, 3).contiguous()
+        T = trip.shape[0]
+        if T:
+            lo, hi_u, hi_i = (int(v) for v in torch.stack((trip.min(), trip[:, 0].max(), trip[:, 1:].max())).tolist())
+            if lo < 0 or hi_u >= n or hi_i >= m:
+                raise IndexError("triplet index out of range for X")
+    else:
+        idx = np.ascontiguousarray(np.asarray(triplets, dtype=np.int64).reshape(-1, 3))
+        T = idx.shape[0]
+        if T and (idx.min() < 0 or idx[:, 0].max() >= n or idx[:, 1:].max() >= m):
+            raise IndexError("triplet index out of range for X")          # as X[u, i] would (structure.py:509)
+        trip = torch.from_numpy(idx.astype(np.int32)).to(device)
     out = torch.empty((T if soft else T * K, 4), dtype=torch.int32, device=device)
     if isinstance(X, torch.Tensor):
         Xd = X.detach().to(device=device, dtype=torch.float32).contiguous()

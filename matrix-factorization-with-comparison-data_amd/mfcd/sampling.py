@@ -121,8 +121,12 @@ def run_law(law, num_triplets, exclude=None, seed=0):
     out = torch.empty((max(want, 0), 3), dtype=torch.int32, device=device)
     if want <= 0:
         return out, 0
-    barred = torch.from_numpy(triplet_keys(sorted(exclude), m)).to(device) if exclude else \
-        torch.empty(0, dtype=torch.int64, device=device)
+    if isinstance(exclude, torch.Tensor):          # int [E, 3] device triplets (what an earlier request returned)
+        e = exclude.to(device=device, dtype=torch.int64).reshape(-1, 3)
+        barred = ((e[:, 0] * m + e[:, 1]) * m + e[:, 2]).contiguous()
+    else:
+        barred = torch.from_numpy(triplet_keys(sorted(exclude), m)).to(device) if exclude else \
+            torch.empty(0, dtype=torch.int64, device=device)
     have = attempts = idle = 0
     stream = _lib.stream_ptr(device)
     while have < want and (law.budget is None or attempts < law.budget):

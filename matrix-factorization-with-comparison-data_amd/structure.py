@@ -296,7 +296,29 @@ def generate_X(n, m, d, device, generation="base", **kwargs):
 
 def split_dataset_from_triplets(X, num_triplets, scale=1.0, K=1, train_ratio=0.8, val_ratio=0.1, batch_size=64,
                                 strategy="random", popularity_method="zipf", alpha=1.5, soft_label=False):
-    """ref:666-742 → (train_loader, val_loader, test_loader)."""
+    """ref:666-742 → (train_loader, val_loader, test_loader).
+
+    With BOTH `set_sampler_device` and `set_label_device` in force (and a strategy that has a device law) the whole
+    chain — triplets, the seed-42 80/10/10 split, the top-up of the test part to 500 rows, the labels and the 16-byte
+    records — stays in HBM ("dataset materialisation on device"); `.data` of the datasets still yields the
+    reference's list of tuples when somebody reads it."""
+    if _SAMPLER_DEVICE is not None and _LABEL_DEVICE is not None and strategy in _sampling.DEVICE_STRATEGIES:
+        kw = dict(popularity_method=popularity_method, alpha=alpha) if strategy == "popularity" else {}
+        trip = _sampling.sample_triplets(X, num_triplets, strategy, None, device=_SAMPLER_DEVICE, **kw)
+        total = trip.shape[0]
+        if total < num_triplets:
+            print(f"⚠️ Only {total} triplets generated for strategy: {strategy} (target={num_triplets})")
+        n_train, n_val = int(train_ratio * total), int(val_ratio * total)
+        order = torch.randperm(total, generator=torch.Generator().manual_seed(42)).to(trip.device)   # random_split's draw
+        tr, va, te = trip[order[:n_train]], trip[order[n_train:n_train + n_val]], trip[order[n_train + n_val:]]
+        if te.shape[0] * K < 500:                                                                # ref:721
+            more = _sampling.sample_triplets(X, (500 + K - 1) // K - te.shape[0], strategy, trip,
+                                             device=_SAMPLER_DEVICE, **kw)
+            te = torch.cat((te, more))
+        mk = lambda t, train: BTLPreferenceDataset(t, X, scale=scale, K=K, soft_label=soft_label, train=train)  # noqa: E731
+        return (DataLoader(mk(tr, True), batch_size=batch_size, shuffle=True),
+                DataLoader(mk(va, False), batch_size=batch_size, shuffle=False),
+                DataLoader(mk(te, False), batch_size=batch_size, shuffle=False))
     triplets = list(get_triplets_from_X(X, num_triplets, strategy=strategy, popularity_method=popularity_method,
                                         alpha=alpha))
     if len(triplets) < num_triplets:

@@ -1156,6 +1156,8 @@ def test_device_sampler_feeds_the_reference_pipeline(dev):
         torch.manual_seed(0)
         for strategy in ("random", "popularity", "top_k", "proximity", "margin"):
             tr, va, te = S.split_dataset_from_triplets(X, 3000, scale=1.0, K=2, strategy=strategy)
+            for ld in (tr, va, te):      # triplets, split, labels and records were made in HBM; nothing on the host yet
+                assert ld.dataset._mfcd_device_records() is not None and ld.dataset._rows is None, strategy
             rows = [np.asarray(ld.dataset.data)[:, :3].astype(np.int64) for ld in (tr, va, te)]
             sets = [{tuple(r) for r in x.tolist()} for x in rows]
             total = sum(len(s_) for s_ in sets)
@@ -1168,6 +1170,14 @@ def test_device_sampler_feeds_the_reference_pipeline(dev):
         torch.manual_seed(1)
         assert a == S.get_triplets_from_X(X, 500, strategy="random")   # seeded through torch's global generator
         assert isinstance(a, set) and all(type(v) is int for t in a for v in t)
+        tr, va, te = S.split_dataset_from_triplets(X, 1000, K=1, strategy="top_k")      # test part topped up to 500 (ref:721)
+        parts = [{tuple(r[:3]) for r in np.asarray(ld.dataset.data).astype(np.int64).tolist()} for ld in (tr, va, te)]
+        assert [len(p_) for p_ in parts] == [800, 100, 500] and not (parts[2] & (parts[0] | parts[1]))
+        import generation_data as gd
+        FX = gd.FactoredMatrix(*gd.generate_embedding_factors(2000, 1500, 8, "cpu", generator=torch.Generator().manual_seed(3)))
+        ftr, fva, fte = S.split_dataset_from_triplets(FX, 20000, K=4, strategy="popularity", soft_label=True)
+        assert len(ftr.dataset) == 16000 and len(fva.dataset) == 2000 * 4 and len(fte.dataset) == 2000 * 4
+        assert ftr.dataset._mfcd_device_records().is_cuda
         tr, va, te = S.split_dataset_from_triplets(X, 6000, K=1, strategy="random")
     finally:
         S.set_sampler_device(None)
