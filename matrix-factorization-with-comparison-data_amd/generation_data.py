@@ -689,10 +689,12 @@ def generate_structured_embeddings(n, m, d, num_clusters=5, cluster_std=0.1, dev
 
 
 def generate_svd_embeddings(n, m, d, noise_level=0.1, device="cpu"):
-    """Top-d SVD factors of a Gaussian matrix, sqrt-spectrum on both sides, plus noise (ref:470-502)."""
+    """Top-d SVD factors of a Gaussian matrix, sqrt-spectrum on both sides, plus noise (ref:470-502).  As the reference
+    computes it: `torch.svd` returns V, which ref:492-496 names `Vt` and slices as `Vt[:d, :].T` — the item factor is
+    therefore the transposed first d ROWS of V, [min(n, m), d]; kept, so that seeded runs give the reference's matrix."""
     Uf, S, Vf = torch.svd(torch.randn(n, m, device=device))
     root = torch.sqrt(S[:d])
-    U, V = Uf[:, :d] * root, Vf[:, :d] * root
+    U, V = Uf[:, :d] * root, Vf[:d, :].T * root
     U = U + noise_level * torch.randn_like(U)
     V = V + noise_level * torch.randn_like(V)
     return U.to(device), V.to(device)
@@ -717,7 +719,9 @@ def _smooth_over_graph(U, influence):
 
 
 def generate_graph_embeddings(n, m, d, device="cpu"):
-    """Two socially-smoothed signal dimensions + 0.1-scale noise dimensions; V / sqrt(d) (ref:539-585)."""
+    """Two socially-smoothed signal dimensions + 0.1-scale noise dimensions; V / sqrt(d) (ref:539-585).  The reference
+    itself raises TypeError here (a stray comma at ref:565 makes `noise` a tuple); this is the evident intent, with the
+    reference's draw order.  The graph comes from networkx, i.e. from Python's `random` module, as there."""
     d_eff = min(d, 2)
     U_low, V_low = torch.randn(n, d_eff, device=device), torch.randn(m, d_eff, device=device)
     U_low = _smooth_over_graph(U_low, 0.3)
