@@ -2,7 +2,7 @@
 """Golden vectors for the seeded triplet samplers (TEST INFRASTRUCTURE — runs in the dev container only).
 
 Imports the *unmodified* reference module /root/reference/generation_data.py, runs its per-attempt sampler loops
-(generation_data.py:16-26 random, 29-43 proximity, 103-128 popularity, 189-224 top_k) under fixed torch / numpy seeds
+(generation_data.py:16-26 random, 29-43 proximity, 87-99 variance, 103-128 popularity, 189-224 top_k, 229-247 cluster) under fixed torch / numpy seeds
 and stores, per case, the inputs, the returned list IN ITS ORDER (the 80/10/10 split indexes into it,
 structure.py:705-718) and one draw from each global generator taken right after the call (so a test can tell that the
 vectorised forms leave both generators where the loops do).  Only data is committed (tests/golden/samplers.npz).
@@ -35,9 +35,12 @@ CASES = [
     ("top_k_a", "top_k", 24, 40, 150, 0, {}),
     ("top_k_short", "top_k", 6, 30, 200, 20, {}),
     ("top_k_k3", "top_k", 20, 12, 60, 10, {"k": 3}),
+    ("variance_a", "variance", 16, 24, 120, 30, {}),
+    ("cluster_a", "cluster", 30, 40, 150, 20, {"n_clusters": 6}),
 ]
 FN = {"random": RG.choose_items_random, "proximity": RG.choose_items_by_proximity,
-      "popularity": RG.choose_items_by_popularity, "top_k": RG.choose_items_top_k}
+      "popularity": RG.choose_items_by_popularity, "top_k": RG.choose_items_top_k,
+      "variance": RG.choose_items_by_variance, "cluster": RG.choose_items_cluster_based}
 
 
 def as_rows(trips):
@@ -59,7 +62,7 @@ def main():
         out[f"{name}.exclude"] = as_rows(excl)
         out[f"{name}.triplets"] = as_rows(got)
         out[f"{name}.after"] = np.asarray([float(torch.rand(1, dtype=torch.float64)), float(np.random.random_sample())])
-        out[f"{name}.meta"] = np.asarray([n, m, want, 2000 + seed, kw.get("k", -1)], dtype=np.int64)
+        out[f"{name}.meta"] = np.asarray([n, m, want, 2000 + seed, kw.get("k", kw.get("n_clusters", -1))], dtype=np.int64)
         out[f"{name}.alpha"] = np.asarray([kw.get("alpha", 0.0)])
         out[f"{name}.method"] = np.asarray(kw.get("method", ""))
         out[f"{name}.strategy"] = np.asarray(strategy)

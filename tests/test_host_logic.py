@@ -247,6 +247,10 @@ def _sampler_call(G, strategy, X, want, excl, k, method, alpha):
         return G.choose_items_by_proximity(X, want, excl, **({"k": k} if k > 0 else {}))
     if strategy == "popularity":
         return G.choose_items_by_popularity(X, want, excl, method=method, alpha=alpha)
+    if strategy == "variance":
+        return G.choose_items_by_variance(X, want, excl)
+    if strategy == "cluster":
+        return G.choose_items_cluster_based(X, want, excl, n_clusters=k)
     return G.choose_items_top_k(X, want, excl, **({"k": k} if k > 0 else {}))
 
 
@@ -258,7 +262,7 @@ def _golden_sampler_cases():
 @pytest.mark.parametrize("name", _golden_sampler_cases()[1])
 def test_seeded_samplers_reproduce_the_reference_lists(name):
     """tests/golden/samplers.npz holds what the UNMODIFIED reference loops returned (oracle/make_golden_samplers.py:
-    generation_data.py:16-26, 29-43, 103-128, 189-224): the bulk forms return the same triplets in the same list order
+    generation_data.py:16-26, 29-43, 87-99, 103-128, 189-224, 229-247): the bulk forms (and the two loops kept as loops) return the same triplets in the same list order
     and leave torch's and numpy's global generators in the same state (probed with one draw each)."""
     import generation_data as G
     z, _ = _golden_sampler_cases()
