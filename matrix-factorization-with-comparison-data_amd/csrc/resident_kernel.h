@@ -290,8 +290,9 @@ void resident_train_kernel(ResidentArgs a)
     // rows, form g, accumulate the row gradients of my rows.  `pos` is the sample's position in the call, `tag` its
     // step's tag.  Returns false when a bounded wait expired.
     // (Requesting the granules one step ahead — an extra event step per hit that only issues the loads — was built
-    // and measured in round 3: same step time with and without it at every window depth; the launch is bound by the
-    // SIMDs' issue slots, not by this round trip, so the simpler form stays.)
+    // and measured in round 3: same step time with and without it at every window depth: the rows a waiting hit waits
+    // for do not exist yet — the launch is bound by the sample stream's dependency chain, one producer -> consumer
+    // hand-off per link (tools/exp_chain_depth.py), not by the round trip of a request — so the simpler form stays.)
     auto process_hit = [&](bool own0, bool own1, bool own2, int lr0, int lr1, int lr2, float zz, int64_t pos,
                            unsigned tag, float inv_batch, int step) MFCD_LAMBDA_INLINE -> bool {
         const bool own[3] = {own0, own1, own2};
@@ -420,8 +421,8 @@ void resident_train_kernel(ResidentArgs a)
         float pr, g;
         if constexpr (FAST) {
             // fast flavour: hardware exponential and reciprocals (<= 1 ulp each) with one Newton correction of each
-            // quotient instead of expf and two IEEE divisions (~60 fewer vector instructions per hit; the launch is
-            // bound by vector issue).  Same operation order as the reference sequence (common.h).
+            // quotient instead of expf and two IEEE divisions (~60 fewer vector instructions per hit, all of them on the
+            // producer -> consumer chain the launch is bound by).  Same operation order as the reference sequence (common.h).
             const float x = wave_sum64(acc);
             const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);      // exp(-x)
             const float dn = 1.0f + e;
@@ -718,7 +719,8 @@ void resident_train_kernel(ResidentArgs a)
             // The step loop is cut at this wave's events: between two of them the wave runs QUIET steps — scalars of the
             // next step requested, dense update with a literal zero gradient, counter — in a loop of its own with no
             // flag, no gradient register and no event test inside (every instruction of this loop is paid by all
-            // waves at every step: the SIMDs' issue slots, not any wave's latency, bound the launch).
+            // waves at every step: it sets the floor under the launch, and a wave on the dependency chain shares its
+            // SIMD's issue slots with three waves running it).
             ScalarTablePtr scp = (ScalarTablePtr)a.sc;             // the table holds K+1 entries (host pads one)
             auto load_scalars_at = [&](ScalarTablePtr f) MFCD_LAMBDA_INLINE {
                 StepScalars x;
