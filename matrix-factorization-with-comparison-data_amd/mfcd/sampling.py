@@ -71,6 +71,8 @@ def build_law(X, num_triplets, strategy, device, popularity_method="zipf", alpha
             var = torch.var(_dense_on(X, device), dim=0).double().cpu().numpy()
             probs = var / var.sum()
             c.pair_rule = 1
+            if not np.isfinite(probs).all() or (probs < 0).any():      # e.g. one user: the unbiased variance is NaN
+                raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # as torch.multinomial (ref:95)
         cdf = np.cumsum(probs)
         cdf /= cdf[-1]
         c.law = LAW_ITEM_CDF
