@@ -361,6 +361,12 @@ int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, float *mV, 
                            const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0, int n,
                            int m, int d, double lr, double beta1, double beta2, double eps, double weight_decay,
                            float *loss_per_step, void *workspace, size_t workspace_bytes, void *comm, void *stream);
+/* the native loop over bf16 factor shards (exchange buffer, moments and arithmetic stay fp32; bit-identical to
+ * mfcd_train_steps_bf16's streaming form with the same batch size) */
+int mfcd_shard_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, float *mV, float *vV,
+                           const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0, int n,
+                           int m, int d, double lr, double beta1, double beta2, double eps, double weight_decay,
+                           float *loss_per_step, void *workspace, size_t workspace_bytes, void *comm, void *stream);
 
 /*
  * Dense UV^T pass against X [n][m] fp32 without materialising UV^T (MFMA fp32 tiles, fused

@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <unordered_map>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -196,12 +197,18 @@ __global__ __launch_bounds__(256) void train_step_kernel(
                 const int uu = __shfl(s.u, tl, MFCD_WAVE), ii = __shfl(s.i, tl, MFCD_WAVE),
                           jj = __shfl(s.j, tl, MFCD_WAVE);
                 const float zz = __shfl(s.z, tl, MFCD_WAVE);
-                const TP *ur = Uin + (int64_t)uu * d, *vi = Vin + (int64_t)ii * d, *vj = Vin + (int64_t)jj * d;
-                if constexpr (MODE == 3) {   // rows of sample base + tl as gathered before this step (fp32 only)
-                    const TP *xb = reinterpret_cast<const TP *>(g_in);
-                    ur = xb + (int64_t)(base + tl) * d;
-                    vi = xb + ((int64_t)g_stride + base + tl) * d;
-                    vj = xb + ((int64_t)2 * g_stride + base + tl) * d;
+                // MODE 3: the rows of sample base + tl as gathered before this step — always fp32 in the exchange buffer
+                // (bf16 tables are widened exactly by the pack kernels)
+                using XT = typename std::conditional<MODE == 3, float, TP>::type;
+                const XT *ur, *vi, *vj;
+                if constexpr (MODE == 3) {
+                    ur = g_in + (int64_t)(base + tl) * d;
+                    vi = g_in + ((int64_t)g_stride + base + tl) * d;
+                    vj = g_in + ((int64_t)2 * g_stride + base + tl) * d;
+                } else {
+                    ur = Uin + (int64_t)uu * d;
+                    vi = Vin + (int64_t)ii * d;
+                    vj = Vin + (int64_t)jj * d;
                 }
                 float g;
                 if (MODE != 3 && g_in) {
@@ -1347,7 +1354,8 @@ extern "C" int mfcd_dp_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, flo
 // (MODE 3 of train_step_kernel) over the shard, in place, with the dense Adam sweep over 1/R of the state.
 namespace {
 
-__global__ __launch_bounds__(256) void shard_pack_kernel(const float *__restrict__ Us, const float *__restrict__ Vs,
+template <typename TP>
+__global__ __launch_bounds__(256) void shard_pack_kernel(const TP *__restrict__ Us, const TP *__restrict__ Vs,
                                                          const mfcd_sample *__restrict__ batch, int Bk, int Bcap, int d,
                                                          int u_off, int nu, int v_off, int nv, float *__restrict__ xbuf,
                                                          int merge)
@@ -1358,7 +1366,7 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const float *__restrict
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // (role, t)
     if (w >= 3 * Bcap) return;
     const int role = w / Bcap, t = w - role * Bcap;
-    const float *src = nullptr;
+    const TP *src = nullptr;
     if (t < Bk) {
         const mfcd_sample s = batch[t];
         const int row = role == 0 ? s.u - u_off : (role == 1 ? s.i : s.j) - v_off;
@@ -1366,7 +1374,7 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const float *__restrict
     }
     if (merge && !src) return;
     float *dst = xbuf + (int64_t)w * d;
-    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] = src ? src[k] : 0.0f;
+    for (int k = lane; k < d; k += MFCD_WAVE) dst[k] = src ? ldf(src, k) : 0.0f;   // bf16 rows widen exactly
 }
 
 // Exchange rows of the NEXT batch, rolled forward over the step that is about to run (the look-ahead rule of the
@@ -1375,7 +1383,8 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const float *__restrict
 // BEFORE the step runs, and the collective of batch k+1 overlaps the step of batch k.  Same adam_update, same operation
 // order as the step kernel: the rolled value equals the in-place one bit for bit (rehearsal tests).  The caller
 // guarantees that no row of `next` is named by the current batch (mfcd_shard_collisions).
-__global__ __launch_bounds__(256) void shard_pack_ahead_kernel(const float *__restrict__ Us, const float *__restrict__ Vs,
+template <typename TP>
+__global__ __launch_bounds__(256) void shard_pack_ahead_kernel(const TP *__restrict__ Us, const TP *__restrict__ Vs,
                                                                const float *__restrict__ mU, const float *__restrict__ vU,
                                                                const float *__restrict__ mV, const float *__restrict__ vV,
                                                                const mfcd_sample *__restrict__ next, int Bk, int Bcap,
@@ -1394,12 +1403,14 @@ __global__ __launch_bounds__(256) void shard_pack_ahead_kernel(const float *__re
     }
     if (merge && src < 0) return;
     float *dst = xbuf + (int64_t)w * d;
-    const float *P = role == 0 ? Us : Vs, *M1 = role == 0 ? mU : mV, *M2 = role == 0 ? vU : vV;
+    const TP *P = role == 0 ? Us : Vs;
+    const float *M1 = role == 0 ? mU : mV, *M2 = role == 0 ? vU : vV;
     for (int k = lane; k < d; k += MFCD_WAVE) {
         float v = 0.0f;
         if (src >= 0) {
-            float p = P[src + k], m1 = M1[src + k], m2 = M2[src + k];
+            float p = ldf(P, src + k), m1 = M1[src + k], m2 = M2[src + k];
             adam_update(p, m1, m2, 0.0f, ac.st, ac.sc);
+            if constexpr (sizeof(TP) == 2) p = (float)(mfcd_bf16)p;   // the step's one rounding point (store_vec)
             v = p;
         }
         dst[k] = v;
@@ -1489,7 +1500,7 @@ extern "C" int mfcd_shard_pack_ahead(const float *U_shard, const float *V_shard,
         return MFCD_EINVAL;
     if ((u_hi > u_lo && (!U_shard || !mU || !vU)) || (v_hi > v_lo && (!V_shard || !mV || !vV))) return MFCD_EINVAL;
     const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step);
-    hipLaunchKernelGGL(shard_pack_ahead_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, U_shard, V_shard,
+    hipLaunchKernelGGL(shard_pack_ahead_kernel<float>, dim3((3 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, U_shard, V_shard,
                        mU, vU, mV, vV, next_batch, Bk, B, d, u_lo, u_hi - u_lo, v_lo, v_hi - v_lo, ac, xbuf, 0);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
@@ -1501,16 +1512,17 @@ extern "C" int mfcd_shard_pack(const float *U_shard, const float *V_shard, const
     if (!batch || !xbuf || Bk < 0 || B <= 0 || Bk > B || d <= 0 || d > MFCD_MAX_D || u_hi < u_lo || v_hi < v_lo)
         return MFCD_EINVAL;
     if ((u_hi > u_lo && !U_shard) || (v_hi > v_lo && !V_shard)) return MFCD_EINVAL;
-    hipLaunchKernelGGL(shard_pack_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, U_shard, V_shard,
+    hipLaunchKernelGGL(shard_pack_kernel<float>, dim3((3 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, U_shard, V_shard,
                        batch, Bk, B, d, u_lo, u_hi - u_lo, v_lo, v_hi - v_lo, xbuf, 0);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }
 
-extern "C" int mfcd_shard_apply(float *U_shard, float *V_shard, float *mU, float *vU, float *mV, float *vV,
-                                const mfcd_sample *batch, int Bk, int B, const float *xbuf, int64_t step, int d,
-                                int u_lo, int u_hi, int v_lo, int v_hi, double lr, double beta1, double beta2,
-                                double eps, double weight_decay, float *loss_terms, void *stream)
+namespace {
+template <typename TP>
+int shard_apply_t(TP *U_shard, TP *V_shard, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *batch, int Bk,
+                  int B, const float *xbuf, int64_t step, int d, int u_lo, int u_hi, int v_lo, int v_hi, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, float *loss_terms, void *stream)
 {
     if (!batch || !xbuf || Bk <= 0 || B <= 0 || Bk > B || d <= 0 || d > MFCD_MAX_D || step < 1) return MFCD_EINVAL;
     const int nu = u_hi - u_lo, nv = v_hi - v_lo;
@@ -1528,17 +1540,29 @@ extern "C" int mfcd_shard_apply(float *U_shard, float *V_shard, float *mU, float
     // an empty table side is legal (a rank may own rows of one table only when world > rows): one dummy row count
     const Plan pl = make_plan(ptrs, 7, nu > 0 ? nu : 0, nv > 0 ? nv : 0, d);
     const AdamConst ac = adam_const(lr, beta1, beta2, eps, weight_decay, step);
-    dispatch_step<3, float>(pl, (hipStream_t)stream, U_shard, V_shard, U_shard, V_shard, mU, vU, mV, vV, batch, xbuf, Bk,
-                            1.0f / (float)Bk, nu, nv, d, ac, loss_terms, nullptr, nullptr, B, u_lo, v_lo);
+    dispatch_step<3, TP>(pl, (hipStream_t)stream, U_shard, V_shard, U_shard, V_shard, mU, vU, mV, vV, batch, xbuf, Bk,
+                         1.0f / (float)Bk, nu, nv, d, ac, loss_terms, nullptr, nullptr, B, u_lo, v_lo);
     MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }
+}  // namespace
 
-extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
-                                      const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0,
-                                      int n, int m, int d, double lr, double beta1, double beta2, double eps,
-                                      double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
-                                      void *comm, void *stream)
+extern "C" int mfcd_shard_apply(float *U_shard, float *V_shard, float *mU, float *vU, float *mV, float *vV,
+                                const mfcd_sample *batch, int Bk, int B, const float *xbuf, int64_t step, int d,
+                                int u_lo, int u_hi, int v_lo, int v_hi, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, float *loss_terms, void *stream)
+{
+    return shard_apply_t<float>(U_shard, V_shard, mU, vU, mV, vV, batch, Bk, B, xbuf, step, d, u_lo, u_hi, v_lo, v_hi, lr,
+                                beta1, beta2, eps, weight_decay, loss_terms, stream);
+}
+
+namespace {
+// fp32 or bf16 factor shards (BASELINE configs[2]'s storage); the exchange buffer, the moments and the arithmetic are fp32
+template <typename TP>
+int run_shard_train_steps(TP *U, TP *V, float *mU, float *vU, float *mV, float *vV, const mfcd_sample *samples, int64_t N,
+                          int B, int rank, int world, int64_t step0, int n, int m, int d, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, float *loss_per_step, void *workspace,
+                          size_t workspace_bytes, void *comm, void *stream)
 {
     if (n <= 0 || m <= 0 || d <= 0 || d > MFCD_MAX_D || N < 0 || B <= 0 || world < 1 || rank < 0 || rank >= world ||
         step0 < 0)
@@ -1574,7 +1598,7 @@ extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, 
             int ul, uh, vl, vh;
             int64_t uo, vo;
             range(r, ul, uh, vl, vh, uo, vo);
-            hipLaunchKernelGGL(shard_pack_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, st, U + uo, V + vo, samples + off, Bk,
+            hipLaunchKernelGGL(shard_pack_kernel<TP>, dim3((3 * B + 3) / 4), dim3(256), 0, st, U + uo, V + vo, samples + off, Bk,
                                B, d, ul, uh - ul, vl, vh - vl, xbuf, (comm || r == r0) ? 0 : 1);
         }
         MFCD_HIP_TRY(hipGetLastError());
@@ -1589,7 +1613,7 @@ extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, 
             int ul, uh, vl, vh;
             int64_t uo, vo;
             range(r, ul, uh, vl, vh, uo, vo);
-            hipLaunchKernelGGL(shard_pack_ahead_kernel, dim3((3 * B + 3) / 4), dim3(256), 0, st, U + uo, V + vo, mU + uo,
+            hipLaunchKernelGGL(shard_pack_ahead_kernel<TP>, dim3((3 * B + 3) / 4), dim3(256), 0, st, U + uo, V + vo, mU + uo,
                                vU + uo, mV + vo, vV + vo, samples + off, Bk, B, d, ul, uh - ul, vl, vh - vl, ac, xbuf,
                                (comm || r == r0) ? 0 : 1);
         }
@@ -1603,9 +1627,9 @@ extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, 
             int ul, uh, vl, vh;
             int64_t uo, vo;
             range(r, ul, uh, vl, vh, uo, vo);
-            if (int rc = mfcd_shard_apply(U + uo, V + vo, mU + uo, vU + uo, mV + vo, vV + vo, samples + off, Bk, B, xbuf,
-                                          step0 + k + 1, d, ul, uh, vl, vh, lr, beta1, beta2, eps, weight_decay,
-                                          r == r0 ? terms + off : nullptr, stream))
+            if (int rc = shard_apply_t<TP>(U + uo, V + vo, mU + uo, vU + uo, mV + vo, vV + vo, samples + off, Bk, B, xbuf,
+                                           step0 + k + 1, d, ul, uh, vl, vh, lr, beta1, beta2, eps, weight_decay,
+                                           r == r0 ? terms + off : nullptr, stream))
                 return rc;
         }
         return 0;
@@ -1701,4 +1725,26 @@ extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, 
         MFCD_HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+}  // namespace
+
+extern "C" int mfcd_shard_train_steps(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                                      const mfcd_sample *samples, int64_t N, int B, int rank, int world, int64_t step0,
+                                      int n, int m, int d, double lr, double beta1, double beta2, double eps,
+                                      double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
+                                      void *comm, void *stream)
+{
+    return run_shard_train_steps<float>(U, V, mU, vU, mV, vV, samples, N, B, rank, world, step0, n, m, d, lr, beta1, beta2,
+                                        eps, weight_decay, loss_per_step, workspace, workspace_bytes, comm, stream);
+}
+
+extern "C" int mfcd_shard_train_steps_bf16(uint16_t *U, uint16_t *V, float *mU, float *vU, float *mV, float *vV,
+                                           const mfcd_sample *samples, int64_t N, int B, int rank, int world,
+                                           int64_t step0, int n, int m, int d, double lr, double beta1, double beta2,
+                                           double eps, double weight_decay, float *loss_per_step, void *workspace,
+                                           size_t workspace_bytes, void *comm, void *stream)
+{
+    return run_shard_train_steps<mfcd_bf16>((mfcd_bf16 *)U, (mfcd_bf16 *)V, mU, vU, mV, vV, samples, N, B, rank, world,
+                                            step0, n, m, d, lr, beta1, beta2, eps, weight_decay, loss_per_step, workspace,
+                                            workspace_bytes, comm, stream);
 }

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mfcd_shard_apply": (_i32, [_vp] * 7 + [_i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp]),
     "mfcd_shard_train_steps": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
                                [_vp, _vp, _sz, _vp, _vp]),
+    "mfcd_shard_train_steps_bf16": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 +
+                               [_vp, _vp, _sz, _vp, _vp]),
     "mfcd_uvt_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "mfcd_uvt_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_uvt_stats_select": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -273,8 +273,9 @@ class NativeShard:
     def __init__(self, binding, group=None, simulate_world=None):
         self.b, self.L = binding, _lib.load()
         U, V = binding.model.U.data, binding.model.V.data
-        if U.dtype != torch.float32:
-            raise NotImplementedError("the row-sharded loop takes fp32 factors")
+        if U.dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError("the row-sharded loop takes fp32 or bf16 factor tables")
+        self.entry = self.L.mfcd_shard_train_steps if U.dtype == torch.float32 else self.L.mfcd_shard_train_steps_bf16
         self.n, self.d, self.m, self.dev = U.shape[0], U.shape[1], V.shape[0], U.device
         self.comm, self.shard, self.group = None, None, group
         if simulate_world is not None:
@@ -302,7 +303,7 @@ class NativeShard:
         tens = self.shard.tensors() if self.shard is not None else self.b.tensors()
         p = lambda t: _lib.ptr(t) if t.numel() else _lib.ptr(self.ws)   # noqa: E731  (an empty shard is never dereferenced)
         lr, b1, b2, eps, wd = self.b.hyper()
-        _lib.check(self.L.mfcd_shard_train_steps(*[p(t) for t in tens], _lib.ptr(stream), N, B, self.rank, self.world,
+        _lib.check(self.entry(*[p(t) for t in tens], _lib.ptr(stream), N, B, self.rank, self.world,
                                                  self.b.step, self.n, self.m, self.d, lr, b1, b2, eps, wd,
                                                  _lib.ptr(loss_out), _lib.ptr(self.ws), self.ws.numel(), self.comm,
                                                  _lib.stream_ptr(self.dev)))
