@@ -294,7 +294,48 @@ class Runner:
         out = [0.0, 0.0, 0.0]
         self.bind.flush()
         self.engine.train_steps(self.bind, stream, B, kernel_us=out)
+        self.last_sample_records = stream          # the records that launch consumed (chain_model below)
         return out
+
+
+def chain_depth(records, B, n):
+    """Longest chain of dependent samples in a record stream (int [N, >= 3] rows of u, i, j): a sample's update reads its
+    three rows as the previous step left them, so it hangs on the latest earlier sample that named any of them
+    (tools/sim_chain_depth.py, tools/exp_chain_depth.py)."""
+    r = np.asarray(records)[:, :3].astype(np.int64)
+    depth = np.zeros(int(max(r[:, 0].max() + 1, n)) + int(r[:, 1:].max()) + 1, dtype=np.int64)
+    off = int(max(r[:, 0].max() + 1, n))
+    longest = 0
+    for k in range(0, r.shape[0], B):
+        a, b, c = r[k:k + B, 0], r[k:k + B, 1] + off, r[k:k + B, 2] + off
+        dd = np.maximum(np.maximum(depth[a], depth[b]), depth[c]) + 1
+        new = depth.copy()
+        np.maximum.at(new, np.concatenate([a, b, c]), np.concatenate([dd, dd, dd]))
+        depth = new
+        longest = max(longest, int(dd.max()))
+    return longest
+
+
+# resident kernel at C2 shape: time per chain link and per-step floor, measured by tools/exp_chain_depth.py
+CHAIN_LINK_US, CHAIN_FLOOR_US, CHAIN_FILE = 1.43, 0.36, "profiles/r03_chain_depth_experiment.txt"
+
+
+def chain_model(cfg, plan, records, steps, measured_us):
+    """`kernel_only.chain_model`: what the measured law of the resident kernel (launch time = floor per step
+    + hand-off latency per link of the sample stream's dependency chain) predicts for the very records the sampled
+    launch consumed, beside what was measured.  C2 shape only (the constants were measured there)."""
+    if cfg.get("name", "C2") != "C2" or plan["form_name"] != "resident" or records is None:
+        return None
+    try:
+        depth = chain_depth(records.cpu().numpy(), cfg["B"], cfg["n"])
+        pred = CHAIN_FLOOR_US * steps + CHAIN_LINK_US * depth
+        return {"chain_depth": depth, "link_us": CHAIN_LINK_US, "floor_us_per_step": CHAIN_FLOOR_US,
+                "predicted_kernel_us": round(pred, 1), "measured_kernel_us": round(measured_us, 2),
+                "measured_over_predicted": round(measured_us / pred, 3), "constants_from": CHAIN_FILE,
+                "note": "a launch is bound by its stream's dependency chain: one producer -> consumer hand-off per link "
+                        "on top of the vector-issue floor; the prediction excludes the launch's start and drain (~3 us)"}
+    except Exception:
+        return None
 
 
 def host_cpu_share():
@@ -682,6 +723,9 @@ def _run(args):
         off = offline_kernel_stats(cfg, plan, kone["steps_per_launch"])
         if off:
             kone["rocprof_offline"] = off
+        cm = chain_model(cfg, plan, getattr(runner, "last_sample_records", None), klen, kone["kernel_launch_us"])
+        if cm:
+            kone["chain_model"] = cm
         out["roofline"]["kernel_only"] = kone
     if ramp:
         out["clock_ramp"] = ramp
