@@ -1,0 +1,299 @@
+// big.hip — register-resident optimiser steps for states of up to 8 388 608 elements at d = 64 (BASELINE configs[3]:
+// n = m = 65536, d = 64 is EXACTLY 1 024 SIMDs x 64 lanes x 128 rows), one MI355X.  Opt-in form (mfcd_train_steps_big).
+//
+// Same step as mfcd_train_steps (structure.py:845-852: forward, BCE, backward, dense coupled-L2 Adam) and the same
+// arithmetic as its streaming form (adam_update, sigmoid_f32, bce_*: results are bit-identical to it), but the Adam state
+// never leaves the chip during a call: ONE persistent launch of 1 024 waves, one per SIMD, each owning 128 rows of the
+// virtual table [U; V]:
+//   * exp_avg and exp_avg_sq of the slice live in 2 x 128 registers per lane (a lone wave addresses 512: the compiler
+//     places what does not fit the 256 architectural VGPRs in AccVGPRs), at compile-time indices of the unrolled sweep;
+//   * the parameters of the slice live in LDS (32 KB per wave, 128 KB per workgroup of four waves), where the sparse
+//     part of the step — hits of the batch on this wave's rows — can address a row by number;
+//   * per step: every wave scans the batch's <= 64 records (one lane per sample), publishes the rows it owns that the
+//     batch names (state after the previous step) as tagged 8-byte granules into the sample's mailbox slot, polls the
+//     slots of the rows it does not own (bounded spins, sticky abort word), forms the coefficient and accumulates its
+//     rows' gradients in batch order (a few LDS slots), then sweeps its 128 rows with the dense update.
+// The sweep is bound by vector issue (128 registers per SIMD; the streaming form moves 24 bytes per element through
+// HBM / the Infinity Cache instead), and C4's uniform streams carry short dependency chains (16-20 links per 1 049
+// steps), so the publish-right-before-use protocol costs little here; a look-ahead window as in resident_kernel.h is
+// not needed.
+#include <vector>
+
+#include "train_common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr int kRows = 128;          // rows (= registers per state array) per wave
+constexpr int kD = 64;
+constexpr int kWaves = 1024;        // one per SIMD of the 256 CUs
+constexpr int kSlots = 16;          // distinct rows of a wave one batch may touch (more: the call is refused)
+constexpr unsigned kSpinLimit = 1u << 22;
+
+struct BigArgs {
+    float *U, *V, *mU, *vU, *mV, *vV;
+    const mfcd_sample *samples;
+    long long N;
+    int B, K, n, m;
+    const StepScalars *sc;          // [K]
+    AdamStatic ac;
+    u64 *mailbox;                   // [N][3][64] granules {tag, fp32}, zeroed before the launch
+    float *terms;                   // [N] BCE terms (the u-owner records)
+    int *status;                    // sticky: 0 ok, 1 a bounded wait expired, 2 more than kSlots rows of a wave in a batch
+};
+
+__device__ __forceinline__ u64 pack(unsigned tag, float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void big_train_kernel(BigArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wave;
+    float *prow = lds + (size_t)wave * kRows * kD;                          // [kRows][64] parameters of my rows
+    float *grad = lds + (size_t)4 * kRows * kD + (size_t)wave * kSlots * kD; // [kSlots][64] sparse row gradients
+    const int Rlo = gw * kRows, R = a.n + a.m;                              // my virtual rows: [Rlo, Rlo + kRows)
+
+    float m1[kRows], m2[kRows];
+#pragma unroll
+    for (int q = 0; q < kRows; ++q) {
+        const int v = Rlo + q;
+        float p = 0.0f;
+        m1[q] = m2[q] = 0.0f;
+        if (v < R) {
+            const bool item = v >= a.n;
+            const long long o = (long long)(item ? v - a.n : v) * kD + lane;
+            p = item ? a.V[o] : a.U[o];
+            m1[q] = item ? a.mV[o] : a.mU[o];
+            m2[q] = item ? a.vV[o] : a.vU[o];
+        }
+        prow[q * kD + lane] = p;
+    }
+
+    bool alive = true;
+    for (int k = 0; k < a.K && alive; ++k) {
+        const long long pos0 = (long long)k * a.B;
+        const int Bk = (int)((a.N - pos0) < a.B ? (a.N - pos0) : a.B);
+        const unsigned tag = (unsigned)k + 1u;
+        const StepScalars sc = a.sc[k];
+        // ---- which samples of the batch name my rows? (one lane per sample, virtual ids: users first, then items)
+        mfcd_sample s;
+        s.u = s.i = s.j = -1;
+        s.z = 0.0f;
+        if (lane < Bk) s = a.samples[pos0 + lane];
+        const int vu = s.u - Rlo, vi = s.i + a.n - Rlo, vj = s.j + a.n - Rlo;
+        const bool ou = lane < Bk && vu >= 0 && vu < kRows;
+        const bool oi = lane < Bk && vi >= 0 && vi < kRows;
+        const bool oj = lane < Bk && vj >= 0 && vj < kRows;
+        const u64 mu = __ballot(ou), mi = __ballot(oi), mj = __ballot(oj);
+        u64 mine = mu | mi | mj;
+        u64 hit_lo = 0, hit_hi = 0;                 // rows of mine the batch names (bit = local row)
+        int nslots = 0;
+        int slot_row[kSlots];
+#pragma unroll
+        for (int x = 0; x < kSlots; ++x) slot_row[x] = -1;
+
+        if (mine) {
+            // ---- publish: my rows as they are after step k-1, into the slots of the samples that name them
+            for (u64 w = mine; w; w &= w - 1) {
+                const int t = __ffsll((long long)w) - 1;
+                u64 *slot = a.mailbox + ((pos0 + t) * 3) * kD + lane;
+                const int ru = __shfl(vu, t, MFCD_WAVE), ri = __shfl(vi, t, MFCD_WAVE), rj = __shfl(vj, t, MFCD_WAVE);
+                if ((mu >> t) & 1ull)
+                    __hip_atomic_store(slot, pack(tag, prow[ru * kD + lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((mi >> t) & 1ull)
+                    __hip_atomic_store(slot + kD, pack(tag, prow[ri * kD + lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((mj >> t) & 1ull)
+                    __hip_atomic_store(slot + 2 * kD, pack(tag, prow[rj * kD + lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ---- hits, in batch order: the other rows from their owners, the coefficient, my rows' gradients
+            const float inv_batch = 1.0f / (float)Bk;
+            for (u64 w = mine; w && alive; w &= w - 1) {
+                const int t = __ffsll((long long)w) - 1;
+                const bool own[3] = {(bool)((mu >> t) & 1ull), (bool)((mi >> t) & 1ull), (bool)((mj >> t) & 1ull)};
+                const int lr[3] = {__shfl(vu, t, MFCD_WAVE), __shfl(vi, t, MFCD_WAVE), __shfl(vj, t, MFCD_WAVE)};
+                const float zz = __shfl(s.z, t, MFCD_WAVE);
+                const u64 *slot = a.mailbox + ((pos0 + t) * 3) * kD + lane;
+                float row[3];
+                unsigned spins = 0;
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        if (own[r]) {
+                            row[r] = prow[lr[r] * kD + lane];
+                        } else {
+                            const u64 g = __hip_atomic_load(slot + r * kD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && (unsigned)(g >> 32) == tag;
+                            row[r] = __uint_as_float((unsigned)g);
+                        }
+                    }
+                    if (__all(ok)) break;
+                    ++spins;
+                    if (spins > kSpinLimit ||
+                        ((spins & 255u) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        if (lane == 0) __hip_atomic_fetch_max(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        alive = false;
+                        break;
+                    }
+                }
+                if (!alive) break;
+                const float x = wave_sum64(row[0] * (row[1] - row[2]));          // d = 64: one product per lane
+                const float pr = sigmoid_f32(x);
+                const float g = bce_sigmoid_backward_f32(pr, zz, inv_batch);
+                if (own[0] && lane == 0) a.terms[pos0 + t] = bce_term_f32(pr, zz);
+                const float contrib[3] = {g * (row[1] - row[2]), g * row[0], -(g * row[0])};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (!own[r]) continue;
+                    int sl = -1;
+#pragma unroll
+                    for (int x2 = 0; x2 < kSlots; ++x2)
+                        if (slot_row[x2] == lr[r]) sl = x2;
+                    if (sl < 0) {
+                        if (nslots == kSlots) {
+                            if (lane == 0) __hip_atomic_fetch_max(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            alive = false;
+                            break;
+                        }
+                        sl = nslots;
+#pragma unroll
+                        for (int x2 = 0; x2 < kSlots; ++x2)
+                            if (x2 == nslots) slot_row[x2] = lr[r];
+                        ++nslots;
+                        grad[sl * kD + lane] = 0.0f;
+                        if (lr[r] < 64) hit_lo |= 1ull << lr[r];
+                        else hit_hi |= 1ull << (lr[r] - 64);
+                    }
+                    grad[sl * kD + lane] += contrib[r];
+                }
+            }
+            if (!alive) break;
+        }
+
+        // ---- dense Adam over my 128 rows; the few rows the batch named take their sparse gradient from LDS
+        // (rows in groups of four, each group's LDS reads issued together and nothing moved across a group's end: the
+        // scheduler would otherwise hoist dozens of reads and spill state registers to make room)
+#pragma unroll
+        for (int q0 = 0; q0 < kRows; q0 += 4) {
+            float pq[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) pq[x] = prow[(q0 + x) * kD + lane];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int q = q0 + x;
+                float g = 0.0f;
+                const u64 hm = q < 64 ? hit_lo : hit_hi;
+                if ((hm >> (q & 63)) & 1ull) {
+                    int sl = 0;
+#pragma unroll
+                    for (int x2 = 0; x2 < kSlots; ++x2)
+                        if (slot_row[x2] == q) sl = x2;
+                    g = grad[sl * kD + lane];
+                }
+                adam_update(pq[x], m1[q], m2[q], g, a.ac, sc);
+                prow[q * kD + lane] = pq[x];
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+
+    // ---- the state goes back to the caller's tables (also after an abort: the status word says what it is worth)
+#pragma unroll
+    for (int q = 0; q < kRows; ++q) {
+        const int v = Rlo + q;
+        if (v < R) {
+            const bool item = v >= a.n;
+            const long long o = (long long)(item ? v - a.n : v) * kD + lane;
+            const float p = prow[q * kD + lane];
+            if (item) { a.V[o] = p; a.mV[o] = m1[q]; a.vV[o] = m2[q]; }
+            else { a.U[o] = p; a.mU[o] = m1[q]; a.vU[o] = m2[q]; }
+        }
+    }
+}
+
+// mean of the batch's BCE terms in the fixed order of the streaming form's batch_mean_kernel (one wave per step)
+__global__ __launch_bounds__(64) void big_batch_mean_kernel(const float *__restrict__ terms, long long N, int B,
+                                                            float *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const long long off = (long long)blockIdx.x * B;
+    const int b = (int)((N - off) < B ? (N - off) : B);
+    float acc = 0.0f;
+    for (int t = lane; t < b; t += MFCD_WAVE) acc += terms[off + t];
+    acc = wave_sum64(acc);
+    if (lane == 0) out[blockIdx.x] = acc / (float)b;
+}
+
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+constexpr size_t kLds = sizeof(float) * ((size_t)4 * kRows * kD + (size_t)4 * kSlots * kD);
+
+}  // namespace
+
+namespace mfcd_detail {
+// train.hip: host-side Adam constants (f64 as Python computes them, rounded where ATen rounds)
+AdamStatic big_adam_static(double beta1, double beta2, double eps, double wd);
+StepScalars big_step_scalars(double lr, double beta1, double beta2, int64_t step);
+}  // namespace mfcd_detail
+
+extern "C" size_t mfcd_train_big_workspace_bytes(int64_t N, int B)
+{
+    if (N <= 0 || B <= 0 || B > 64) return 0;
+    const size_t K = (size_t)((N + B - 1) / B);
+    return 256 + up256(sizeof(StepScalars) * K) + up256(sizeof(float) * (size_t)N) + up256(sizeof(u64) * (size_t)N * 3 * kD);
+}
+
+extern "C" int mfcd_train_steps_big(float *U, float *V, float *mU, float *vU, float *mV, float *vV,
+                                    const mfcd_sample *samples, int64_t N, int B, int64_t step0, int n, int m, int d,
+                                    double lr, double beta1, double beta2, double eps, double weight_decay,
+                                    float *loss_per_step, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!U || !V || !mU || !vU || !mV || !vV || N < 0 || step0 < 0 || n <= 0 || m <= 0) return MFCD_EINVAL;
+    if (d != kD || B <= 0 || B > 64 || (int64_t)n + m > (int64_t)kWaves * kRows) return MFCD_EINVAL;
+    if (N == 0) return 0;
+    if (!samples || !workspace) return MFCD_EINVAL;
+    if (workspace_bytes < mfcd_train_big_workspace_bytes(N, B)) return MFCD_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = (int)((N + B - 1) / B);
+    // one wave per SIMD, all of them resident at once: the polls rely on it
+    static int checked = 0;
+    if (!checked) {
+        int dev = 0, cus = 0, nb = 0;
+        MFCD_HIP_TRY(hipGetDevice(&dev));
+        MFCD_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)big_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        MFCD_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, big_train_kernel, 256, kLds));
+        if (cus * nb < kWaves / 4) return MFCD_EINVAL;
+        checked = 1;
+    }
+    char *ws = (char *)workspace;
+    int *status = (int *)ws;
+    StepScalars *sc_dev = (StepScalars *)(ws + 256);
+    float *terms = (float *)((char *)sc_dev + up256(sizeof(StepScalars) * (size_t)K));
+    u64 *mailbox = (u64 *)((char *)terms + up256(sizeof(float) * (size_t)N));
+    std::vector<StepScalars> sc((size_t)K);
+    for (int k = 0; k < K; ++k) sc[(size_t)k] = mfcd_detail::big_step_scalars(lr, beta1, beta2, step0 + k + 1);
+    MFCD_HIP_TRY(hipMemcpyAsync(sc_dev, sc.data(), sizeof(StepScalars) * (size_t)K, hipMemcpyHostToDevice, st));
+    MFCD_HIP_TRY(hipStreamSynchronize(st));          // (the table is on this call's stack)
+    MFCD_HIP_TRY(hipMemsetAsync(status, 0, 256, st));
+    MFCD_HIP_TRY(hipMemsetAsync(mailbox, 0, sizeof(u64) * (size_t)N * 3 * kD, st));
+    BigArgs a{U, V, mU, vU, mV, vV, samples, (long long)N, B, K, n, m, sc_dev,
+              mfcd_detail::big_adam_static(beta1, beta2, eps, weight_decay), mailbox, terms, status};
+    hipLaunchKernelGGL(big_train_kernel, dim3(kWaves / 4), dim3(256), kLds, st, a);
+    MFCD_HIP_TRY(hipGetLastError());
+    if (loss_per_step) {
+        hipLaunchKernelGGL(big_batch_mean_kernel, dim3((unsigned)K), dim3(64), 0, st, terms, (long long)N, B, loss_per_step);
+        MFCD_HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// status word of the last call on this workspace (device int32 at the workspace's start): 0 ok, 1 a bounded wait expired,
+// 2 a batch named more than 16 distinct rows of one wave (the call is not valid for this sample stream)
+extern "C" int mfcd_train_big_status(const void *workspace, int *status_out, void *stream)
+{
+    if (!workspace || !status_out) return MFCD_EINVAL;
+    MFCD_HIP_TRY(hipMemcpyAsync(status_out, workspace, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MFCD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}

@@ -391,6 +391,13 @@ StepScalars step_scalars(double lr, double beta1, double beta2, int64_t step)
     return s;
 }
 
+}  // namespace
+namespace mfcd_detail {   // big.hip builds its own per-step table
+AdamStatic big_adam_static(double beta1, double beta2, double eps, double wd) { return adam_static(beta1, beta2, eps, wd); }
+StepScalars big_step_scalars(double lr, double beta1, double beta2, int64_t step) { return step_scalars(lr, beta1, beta2, step); }
+}  // namespace mfcd_detail
+namespace {
+
 AdamConst adam_const(double lr, double beta1, double beta2, double eps, double wd, int64_t step)
 {
     AdamConst ac;

@@ -140,6 +140,48 @@ class AdamBinding:
             pass
 
 
+class BigResident:
+    """Opt-in step form for states of up to 8 388 608 elements at d = 64 (include/mfcd.h: mfcd_train_steps_big; BASELINE
+    configs[3] on ONE GPU): the Adam moments of the whole model in registers, the parameters in LDS, one persistent launch
+    per call.  Same results as the streaming form, bit for bit."""
+
+    def __init__(self, binding):
+        self.b, self.L = binding, _lib.load()
+        U, V = binding.model.U.data, binding.model.V.data
+        if U.dtype != torch.float32 or U.shape[1] != 64 or U.shape[0] + V.shape[0] > 131072:
+            raise NotImplementedError("the big resident form takes fp32 tables with d == 64 and n + m <= 131072")
+        self.dev, self.ws = U.device, None
+
+    def train_steps(self, stream, B, loss_out=None):
+        import ctypes
+        U, V, mU, vU, mV, vV = self.b.tensors()
+        N = stream.shape[0]
+        nsteps = (N + B - 1) // B
+        if loss_out is None:
+            loss_out = torch.empty(max(nsteps, 1), dtype=torch.float32, device=self.dev)
+        need = self.L.mfcd_train_big_workspace_bytes(N, B)
+        if need == 0:
+            raise _lib.MfcdError("the big resident form takes batches of at most 64 samples")
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(int(need), dtype=torch.uint8, device=self.dev)
+        lr, b1, b2, eps, wd = self.b.hyper()
+        _lib.check(self.L.mfcd_train_steps_big(_lib.ptr(U), _lib.ptr(V), _lib.ptr(mU), _lib.ptr(vU), _lib.ptr(mV),
+                                               _lib.ptr(vV), _lib.ptr(stream), N, B, self.b.step, U.shape[0], V.shape[0],
+                                               64, lr, b1, b2, eps, wd, _lib.ptr(loss_out), _lib.ptr(self.ws),
+                                               self.ws.numel(), _lib.stream_ptr(self.dev)))
+        self.b.advance(nsteps)
+        return loss_out[:nsteps]
+
+    def status(self):
+        import ctypes
+        out = ctypes.c_int(0)
+        _lib.check(self.L.mfcd_train_big_status(_lib.ptr(self.ws), ctypes.byref(out), _lib.stream_ptr(self.dev)))
+        if out.value:
+            raise _lib.MfcdError({1: "big resident form: a bounded wait expired",
+                                  2: "big resident form: a batch named more than 16 distinct rows of one wave"}.get(
+                                      out.value, f"big resident form: status {out.value}"))
+
+
 def generate_labels(triplets, X, scale=1.0, K=1, soft=False, seed=0, device=None):
     """BTL labels drawn ON the device (include/mfcd.h: mfcd_generate_labels) → int32 [N, 4] device tensor
     of mfcd_sample records (N = T*K hard-label rows, or T soft-label rows), ready for SampleStore / train_steps.

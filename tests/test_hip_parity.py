@@ -1188,6 +1188,54 @@ def test_device_sampler_feeds_the_reference_pipeline(dev):
     assert np.isfinite(tl).all() and tl[-1] < tl[0]
 
 
+@pytest.mark.parametrize("n,m,N,B", [(16384, 16384, 64 * 12 + 5, 64), (30000, 20000, 64 * 30 + 1, 64),
+                                     (65536, 65536, 64 * 40 + 9, 64), (8192, 8192, 16 * 50 + 3, 16)])
+def test_big_resident_form_is_bit_identical_to_the_streaming_step(dev, n, m, N, B):
+    """mfcd_train_steps_big (moments of the whole model in registers, parameters in LDS, one wave per SIMD; fourth case:
+    BASELINE configs[3]'s full table shape, 8 388 608 elements) uses the streaming form's arithmetic: parameters, both
+    moments and the step losses must equal it BIT FOR BIT, over two calls (state written back and reloaded)."""
+    from mfcd import engine
+    d = 64
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=n % 97 + B)
+    st = _records(u, i, j, z, n, m, dev)
+    engine.set_train_path("streaming")
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        bind = engine.AdamBinding(model, opt)
+        ref1 = engine.train_steps(bind, st.dev, B).clone()
+        ref2 = engine.train_steps(bind, st.dev, B).clone()
+    finally:
+        engine.set_train_path("auto")
+    m2, o2 = _model_from(U0, V0, dev, 1e-3, 1e-5)
+    big = engine.BigResident(engine.AdamBinding(m2, o2))
+    l1 = big.train_steps(st.dev, B).clone()
+    big.status()
+    l2 = big.train_steps(st.dev, B).clone()
+    big.status()
+    assert torch.equal(l1, ref1) and torch.equal(l2, ref2)
+    assert torch.equal(m2.U.data, model.U.data) and torch.equal(m2.V.data, model.V.data)
+    for prm, prm2 in ((model.U, m2.U), (model.V, m2.V)):
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(opt.state[prm][key], o2.state[prm2][key]), key
+
+
+def test_big_resident_form_refuses_streams_that_concentrate_on_one_wave(dev):
+    """A small table puts dozens of a batch's rows into one wave's slice: the form says so (status 2 -> MfcdError)
+    instead of running out of gradient slots; shapes it does not take raise NotImplementedError."""
+    from mfcd import engine, _lib
+    U0, V0, u, i, j, z = _synthetic(300, 200, 64, 64 * 3, seed=4)
+    st = _records(u, i, j, z, 300, 200, dev)
+    mdl, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+    big = engine.BigResident(engine.AdamBinding(mdl, opt))
+    big.train_steps(st.dev, 64)
+    with pytest.raises(_lib.MfcdError):
+        big.status()
+    U1, V1, *_ = _synthetic(50, 40, 32, 64, seed=5)
+    m1, o1 = _model_from(U1, V1, dev, 1e-3, 1e-5)
+    with pytest.raises(NotImplementedError):
+        engine.BigResident(engine.AdamBinding(m1, o1))
+
+
 # --------------------------------------------------------------------------------------------------
 # (h) VERDICT r1 item 5: row-sharded state, batch 64 (strong scaling), results equal to one GPU
 # --------------------------------------------------------------------------------------------------
