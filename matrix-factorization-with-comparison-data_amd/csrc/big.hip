@@ -44,6 +44,9 @@ struct BigArgs {
 
 __device__ __forceinline__ u64 pack(unsigned tag, float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); }
 
+// FAST: the resident form's arithmetic (hardware sqrt / rcp / exp2 with one Newton correction per quotient, packed pairs:
+// a few ulp from the IEEE sequence, ~3x fewer issue slots); !FAST: the streaming form's IEEE sequence, bit-identical to it.
+template <bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void big_train_kernel(BigArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -138,8 +141,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 if (!alive) break;
                 const float x = wave_sum64(row[0] * (row[1] - row[2]));          // d = 64: one product per lane
-                const float pr = sigmoid_f32(x);
-                const float g = bce_sigmoid_backward_f32(pr, zz, inv_batch);
+                float pr, g;
+                if constexpr (FAST) {      // as resident_kernel.h's fast hit path
+                    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);      // exp(-x)
+                    const float dn = 1.0f + e;
+                    pr = div_newton(1.0f, dn, __builtin_amdgcn_rcpf(dn));
+                    pr = (e == __builtin_inff()) ? 0.0f : pr;
+                    const float den = fmaxf((1.0f - pr) * pr, 1e-12f);
+                    const float num = inv_batch * (pr - zz);
+                    g = div_newton(num, den, __builtin_amdgcn_rcpf(den)) * (1.0f - pr) * pr;
+                } else {
+                    pr = sigmoid_f32(x);
+                    g = bce_sigmoid_backward_f32(pr, zz, inv_batch);
+                }
                 if (own[0] && lane == 0) a.terms[pos0 + t] = bce_term_f32(pr, zz);
                 const float contrib[3] = {g * (row[1] - row[2]), g * row[0], -(g * row[0])};
 #pragma unroll
@@ -175,24 +189,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // scheduler would otherwise hoist dozens of reads and spill state registers to make room)
 #pragma unroll
         for (int q0 = 0; q0 < kRows; q0 += 4) {
-            float pq[4];
+            float pq[4], gq[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) pq[x] = prow[(q0 + x) * kD + lane];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int q = q0 + x;
-                float g = 0.0f;
+                gq[x] = 0.0f;
                 const u64 hm = q < 64 ? hit_lo : hit_hi;
                 if ((hm >> (q & 63)) & 1ull) {
                     int sl = 0;
 #pragma unroll
                     for (int x2 = 0; x2 < kSlots; ++x2)
                         if (slot_row[x2] == q) sl = x2;
-                    g = grad[sl * kD + lane];
+                    gq[x] = grad[sl * kD + lane];
                 }
-                adam_update(pq[x], m1[q], m2[q], g, a.ac, sc);
-                prow[q * kD + lane] = pq[x];
             }
+            if constexpr (FAST) {
+                adam_update_fast2(pq[0], pq[1], m1[q0], m1[q0 + 1], m2[q0], m2[q0 + 1], gq[0], gq[1], a.ac, sc);
+                adam_update_fast2(pq[2], pq[3], m1[q0 + 2], m1[q0 + 3], m2[q0 + 2], m2[q0 + 3], gq[2], gq[3], a.ac, sc);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) adam_update(pq[x], m1[q0 + x], m2[q0 + x], gq[x], a.ac, sc);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) prow[(q0 + x) * kD + lane] = pq[x];
             asm volatile("" ::: "memory");
         }
     }
@@ -256,15 +277,17 @@ extern "C" int mfcd_train_steps_big(float *U, float *V, float *mU, float *vU, fl
     hipStream_t st = (hipStream_t)stream;
     const int K = (int)((N + B - 1) / B);
     // one wave per SIMD, all of them resident at once: the polls rely on it
-    static int checked = 0;
-    if (!checked) {
+    const bool fast = mfcd_detail::g_resident_math != 0;      // mfcd_set_resident_math: 1 = fast (default), 0 = IEEE
+    auto kernel = fast ? big_train_kernel<true> : big_train_kernel<false>;
+    static int checked[2] = {0, 0};
+    if (!checked[fast]) {
         int dev = 0, cus = 0, nb = 0;
         MFCD_HIP_TRY(hipGetDevice(&dev));
         MFCD_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)big_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-        MFCD_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, big_train_kernel, 256, kLds));
+        MFCD_HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        MFCD_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, kLds));
         if (cus * nb < kWaves / 4) return MFCD_EINVAL;
-        checked = 1;
+        checked[fast] = 1;
     }
     char *ws = (char *)workspace;
     int *status = (int *)ws;
@@ -279,7 +302,7 @@ extern "C" int mfcd_train_steps_big(float *U, float *V, float *mU, float *vU, fl
     MFCD_HIP_TRY(hipMemsetAsync(mailbox, 0, sizeof(u64) * (size_t)N * 3 * kD, st));
     BigArgs a{U, V, mU, vU, mV, vV, samples, (long long)N, B, K, n, m, sc_dev,
               mfcd_detail::big_adam_static(beta1, beta2, eps, weight_decay), mailbox, terms, status};
-    hipLaunchKernelGGL(big_train_kernel, dim3(kWaves / 4), dim3(256), kLds, st, a);
+    hipLaunchKernelGGL(kernel, dim3(kWaves / 4), dim3(256), kLds, st, a);
     MFCD_HIP_TRY(hipGetLastError());
     if (loss_per_step) {
         hipLaunchKernelGGL(big_batch_mean_kernel, dim3((unsigned)K), dim3(64), 0, st, terms, (long long)N, B, loss_per_step);
