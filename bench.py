@@ -165,12 +165,15 @@ def roofline_record(cfg, plan, period_us, kernel_us=None, kernel_step_us=None):
                          f"({plan['streaming_blocks']} workgroups; one launch per optimiser step)"}
     else:
         cyc = algorithmic_valu_cycles_per_step(cfg)
-        simds = SIMDS if plan["form_name"] == "resident" else 4      # the local form runs on ONE CU
+        simds = SIMDS if plan["form_name"] in ("resident", "big-resident") else 4      # the local form runs on ONE CU
         peak = simds * CLOCK_GHZ                                     # G issue-cycles per second
         ach = cyc / (period_us * 1e-6) / 1e9
         kern = (f"resident_train_kernel<D={cfg['d']},Q={plan['resident_q']},LOOK={plan['resident_lookahead']},"
                 f"{'fast' if plan['fast_math'] else 'ieee'}> ({plan['resident_waves']} waves; persistent: one launch per "
                 "call, figures are per optimiser step = launch time / steps)") if plan["form_name"] == "resident" else \
+               (f"big_train_kernel<{'fast' if plan['fast_math'] else 'ieee'}> (csrc/big.hip: 1024 waves, one per SIMD, 128 rows "
+                "each; moments in 256 registers per lane, parameters in LDS; persistent: one launch per call, figures are "
+                "per optimiser step = call time / steps)") if plan["form_name"] == "big-resident" else \
                "local_train_kernel (one workgroup, parameters in LDS; persistent: one launch per call)"
         rec = {"bound": "valu-issue", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "Gcycle/s",
                "frac": round(ach / peak, 4), "traffic": None,
@@ -695,6 +698,10 @@ def _run(args):
     # the form the timed calls took: the longest call of the timed region decides what the record describes
     longest = max((k for _, _, k in runner.train_events), default=args.steps)
     plan = engine.train_plan(min(longest * cfg["B"], runner.train.N), cfg["B"], cfg["n"], cfg["m"], cfg["d"], bf16=bf16)
+    big = getattr(runner.bind, "_big", None)
+    used_big = bool(big) and big.ws is not None and longest >= engine.BIG_MIN_STEPS     # engine.train_steps took csrc/big.hip
+    if used_big:
+        plan = dict(plan, form_name="big-resident")
     out = {
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 6),
@@ -706,7 +713,7 @@ def _run(args):
                    "train_samples": runner.train.N, "parallelism": "single", "step_form": plan["form_name"]},
     }
     kstep = kone = None
-    if not bf16:
+    if not bf16 and not used_big:       # (the timed twin exists for the library's own forms; the big form is priced on the call)
         # the dominant kernel alone, for a call of the timed call's length: HIP event pair directly around its launch inside
         # the library (mfcd_train_steps_timed).  This is the figure a `rocprofv3 --kernel-trace --stats` of the same command
         # shows as that kernel's average duration, and what `achieved` / `frac` are priced on; `call_level` brackets the

@@ -516,6 +516,11 @@ int mfcd_train_steps_big(float *U, float *V, float *mU, float *vU, float *mV, fl
                          double eps, double weight_decay, float *loss_per_step, void *workspace, size_t workspace_bytes,
                          void *stream);
 int mfcd_train_big_status(const void *workspace, int *status_out, void *stream);
+/* pre-check of a sample stream for the form above: *max_out_dev (device int32) = the largest number of row references
+ * one wave's 128-row slice receives from one batch (an upper bound of the distinct rows); the form takes the call when
+ * it is <= mfcd_train_big_slots(). */
+int mfcd_train_big_slots(void);
+int mfcd_train_big_check(const mfcd_sample *samples, int64_t N, int B, int n, int m, int *max_out_dev, void *stream);
 
 #ifdef __cplusplus
 }

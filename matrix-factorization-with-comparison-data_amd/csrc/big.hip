@@ -245,6 +245,32 @@ __global__ __launch_bounds__(64) void big_batch_mean_kernel(const float *__restr
     if (lane == 0) out[blockIdx.x] = acc / (float)b;
 }
 
+// per step: row references of the batch per wave slice (an upper bound of the distinct rows a wave must hold gradient
+// slots for); the maximum over the call goes to *max_out
+__global__ __launch_bounds__(256) void big_check_kernel(const mfcd_sample *__restrict__ samples, long long N, int B, int n,
+                                                        int *__restrict__ max_out)
+{
+    __shared__ int bins[kWaves];
+    for (int x = threadIdx.x; x < kWaves; x += 256) bins[x] = 0;
+    __syncthreads();
+    const long long off = (long long)blockIdx.x * B;
+    const int b = (int)((N - off) < B ? (N - off) : B);
+    for (int x = threadIdx.x; x < 3 * b; x += 256) {
+        const mfcd_sample s = samples[off + x / 3];
+        const int role = x % 3;
+        const int v = role == 0 ? s.u : n + (role == 1 ? s.i : s.j);
+        if (v >= 0 && (v >> 7) < kWaves) atomicAdd(&bins[v >> 7], 1);
+    }
+    __syncthreads();
+    int mx = 0;
+    for (int x = threadIdx.x; x < kWaves; x += 256) mx = bins[x] > mx ? bins[x] : mx;
+    for (int o = 32; o > 0; o >>= 1) {
+        const int y = __shfl_xor(mx, o, MFCD_WAVE);
+        mx = y > mx ? y : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(max_out, mx);
+}
+
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 constexpr size_t kLds = sizeof(float) * ((size_t)4 * kRows * kD + (size_t)4 * kSlots * kD);
@@ -318,5 +344,23 @@ extern "C" int mfcd_train_big_status(const void *workspace, int *status_out, voi
     if (!workspace || !status_out) return MFCD_EINVAL;
     MFCD_HIP_TRY(hipMemcpyAsync(status_out, workspace, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     MFCD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// Largest number of row references one wave's slice receives from one batch of the stream (device int32, zeroed here):
+// the form takes a call when this is <= mfcd_train_big_slots() (an upper bound of the distinct rows, so the test is
+// conservative).  Enqueued on `stream`; the caller reads *max_out_dev.
+extern "C" int mfcd_train_big_slots(void) { return kSlots; }
+
+extern "C" int mfcd_train_big_check(const mfcd_sample *samples, int64_t N, int B, int n, int m, int *max_out_dev,
+                                    void *stream)
+{
+    if (!samples || !max_out_dev || N <= 0 || B <= 0 || B > 64 || n <= 0 || m <= 0 || (int64_t)n + m > (int64_t)kWaves * kRows)
+        return MFCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    MFCD_HIP_TRY(hipMemsetAsync(max_out_dev, 0, sizeof(int), st));
+    hipLaunchKernelGGL(big_check_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(256), 0, st, samples, (long long)N, B, n,
+                       max_out_dev);
+    MFCD_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -69,6 +69,8 @@ SIGNATURES = {
     "mfcd_train_big_workspace_bytes": (_sz, [_i64, _i32]),
     "mfcd_train_steps_big": (_i32, [_vp] * 7 + [_i64, _i32, _i64, _i32, _i32, _i32] + [_dbl] * 5 + [_vp, _vp, _sz, _vp]),
     "mfcd_train_big_status": (_i32, [_vp, ctypes.POINTER(ctypes.c_int), _vp]),
+    "mfcd_train_big_slots": (_i32, []),
+    "mfcd_train_big_check": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "mfcd_sample_workspace_bytes": (_sz, [_i64, _i64]),
     "mfcd_sample_triplets": (_i32, [_vp, _vp, _i64, _i64, _i64, ctypes.c_uint64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mfcd_spearman_max_columns": (_i32, []),

@@ -103,6 +103,7 @@ class AdamBinding:
     def refresh(self):
         self._ctx = None
         self._fast = None
+        self._big = None
         self.drop_prepared()
 
     # ---- prepared calls (include/mfcd.h: mfcd_train_call_*) ----
@@ -140,6 +141,43 @@ class AdamBinding:
             pass
 
 
+import weakref
+
+_big_forms = weakref.WeakSet()          # live BigResident objects: check_status() reads their status words too
+_BIG_MODE = "auto"                      # "auto": train_steps takes the big resident form where it applies; "off"; "force"
+BIG_MIN_STEPS = 256                     # shorter calls stay with the streaming form (state load / write-back, mailbox clear)
+
+
+def set_big_resident(mode):
+    """"auto" (default): `train_steps` uses the big resident form (BigResident) for fp32 models with d == 64 whose state
+    is too large for the regular resident form but fits one GPU's registers (n + m <= 131072: BASELINE configs[3]),
+    for calls of at least BIG_MIN_STEPS steps of at most 64 samples whose stream passes the form's pre-check;
+    "off": never; "force": whenever the shape allows (tests)."""
+    global _BIG_MODE
+    if mode not in ("auto", "off", "force"):
+        raise ValueError(mode)
+    _BIG_MODE = mode
+
+
+def _big_for(binding, N, batch_size, samples_dev):
+    """The binding's BigResident if this call should take it, else None."""
+    if _BIG_MODE == "off" or batch_size > 64:
+        return None
+    big = getattr(binding, "_big", None)
+    if big is None:
+        U, V = binding.model.U.data, binding.model.V.data
+        ok = U.dtype == torch.float32 and U.shape[1] == 64 and U.shape[0] + V.shape[0] <= 131072
+        if ok and _BIG_MODE == "auto":      # only where the library itself would stream (state beyond the resident form)
+            ok = train_plan(max(N, BIG_MIN_STEPS * batch_size), batch_size, U.shape[0], V.shape[0], 64)["form_name"] == "streaming"
+        big = binding._big = BigResident(binding) if ok else False
+    if big is False:
+        return None
+    nsteps = (N + batch_size - 1) // batch_size
+    if _BIG_MODE == "auto" and (nsteps < BIG_MIN_STEPS or TRAIN_PATH_NOW[0] != "auto"):
+        return None
+    return big if big.takes(samples_dev, batch_size) else None
+
+
 class BigResident:
     """Opt-in step form for states of up to 8 388 608 elements at d = 64 (include/mfcd.h: mfcd_train_steps_big; BASELINE
     configs[3] on ONE GPU): the Adam moments of the whole model in registers, the parameters in LDS, one persistent launch
@@ -151,9 +189,9 @@ class BigResident:
         if U.dtype != torch.float32 or U.shape[1] != 64 or U.shape[0] + V.shape[0] > 131072:
             raise NotImplementedError("the big resident form takes fp32 tables with d == 64 and n + m <= 131072")
         self.dev, self.ws = U.device, None
+        _big_forms.add(self)
 
-    def train_steps(self, stream, B, loss_out=None):
-        import ctypes
+    def train_steps(self, stream, B, loss_out=None, defer_step=False):
         U, V, mU, vU, mV, vV = self.b.tensors()
         N = stream.shape[0]
         nsteps = (N + B - 1) // B
@@ -169,11 +207,25 @@ class BigResident:
                                                _lib.ptr(vV), _lib.ptr(stream), N, B, self.b.step, U.shape[0], V.shape[0],
                                                64, lr, b1, b2, eps, wd, _lib.ptr(loss_out), _lib.ptr(self.ws),
                                                self.ws.numel(), _lib.stream_ptr(self.dev)))
-        self.b.advance(nsteps)
+        self.b.advance(nsteps, defer_step)
         return loss_out[:nsteps]
+
+    def takes(self, stream, B):
+        """Pre-check of a record stream (mfcd_train_big_check; one small kernel and a host read): no batch sends more
+        row references into one wave's slice than the kernel has gradient slots for."""
+        N = stream.shape[0]
+        if N == 0 or B > 64:
+            return False
+        worst = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        U, V = self.b.model.U.data, self.b.model.V.data
+        _lib.check(self.L.mfcd_train_big_check(_lib.ptr(stream), N, B, U.shape[0], V.shape[0], _lib.ptr(worst),
+                                               _lib.stream_ptr(self.dev)))
+        return int(worst.item()) <= self.L.mfcd_train_big_slots()
 
     def status(self):
         import ctypes
+        if self.ws is None:
+            return
         out = ctypes.c_int(0)
         _lib.check(self.L.mfcd_train_big_status(_lib.ptr(self.ws), ctypes.byref(out), _lib.stream_ptr(self.dev)))
         if out.value:
@@ -406,9 +458,13 @@ TRAIN_PATHS = {"auto": 0, "streaming": 1, "resident": 2, "local": 3}
 FORM_NAMES = {1: "streaming", 2: "resident", 3: "local"}
 
 
+TRAIN_PATH_NOW = ["auto"]
+
+
 def set_train_path(mode):
     """Select the form of the fused step: "auto" (default), "streaming", "resident" or "local" (include/mfcd.h)."""
     _lib.check(_lib.load().mfcd_set_train_path(TRAIN_PATHS[mode]))
+    TRAIN_PATH_NOW[0] = mode
 
 
 def set_resident_math(flavour):
@@ -446,6 +502,8 @@ def check_status():
     if bad is not None:
         raise _lib.MfcdError(f"resident training kernel aborted (status {bad}): a bounded in-kernel wait expired; "
                              "parameters are undefined")
+    for big in list(_big_forms):
+        big.status()
 
 
 class _FastCall:
@@ -482,7 +540,8 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None,
         fc = binding._fast
         if fc is not None and fc.still_valid(N, batch_size) and samples_dev.is_contiguous():
             nsteps = (N + batch_size - 1) // batch_size
-            if nsteps <= fc.k_cap:
+            # (a binding whose shape the big resident form takes leaves this fast path for calls long enough for it)
+            if nsteps <= fc.k_cap and not (getattr(binding, "_big", False) and nsteps >= BIG_MIN_STEPS and _BIG_MODE != "off"):
                 if loss_out is None:
                     loss_out = torch.empty(nsteps, dtype=torch.float32, device=fc.dev)
                 stream = _raw_stream(fc.dev_index) if _raw_stream is not None else _lib.stream_ptr(fc.dev)
@@ -499,6 +558,12 @@ def train_steps(binding, samples_dev, batch_size, loss_out=None, kernel_us=None,
     nsteps = (N + batch_size - 1) // batch_size
     if N == 0:
         return torch.empty(0, dtype=torch.float32, device=dev) if loss_out is None else loss_out[:0]
+    if getattr(binding, "_big", None) is None and d != 64:
+        binding._big = False                                      # decided once per binding (refresh() clears it)
+    if kernel_us is None and getattr(binding, "_big", None) is not False:
+        big = _big_for(binding, N, batch_size, samples_dev)      # C4-sized states: the big resident form (csrc/big.hip)
+        if big is not None:
+            return big.train_steps(samples_dev, batch_size, loss_out, defer_step)
     if loss_out is None:
         loss_out = torch.empty(nsteps, dtype=torch.float32, device=dev)
     wso = workspace_for(dev, (n, m, d))

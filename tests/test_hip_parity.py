@@ -1231,6 +1231,44 @@ def test_big_resident_form_is_bit_identical_to_the_streaming_step(dev, n, m, N, 
             assert_close_with_rare_outliers(got.data.cpu().numpy(), want.data.cpu().numpy(), 2e-6, 1e-3, nm)
 
 
+def test_auto_takes_the_big_resident_form_for_c4_sized_states(dev):
+    """engine.train_steps under "auto": a C4-shaped fp32 model (state beyond the regular resident form, d = 64) runs
+    calls of >= 256 steps through the big resident form (pre-check of the stream included), shorter calls and
+    `set_big_resident("off")` through the streaming form; results agree with the streaming form within the resident
+    tolerance, and the fast path of later calls does not bypass the choice."""
+    from mfcd import engine
+    n = m = 65536
+    d, B = 64, 64
+    N = B * 300
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=77)
+    st = _records(u, i, j, z, n, m, dev)
+    engine.set_big_resident("off")
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        b0 = engine.AdamBinding(model, opt)
+        engine.train_steps(b0, st.dev[: B * 20], B)
+        ref = engine.train_steps(b0, st.dev, B).clone()
+        assert getattr(b0, "_big", None) in (None, False) or b0._big.ws is None
+    finally:
+        engine.set_big_resident("auto")
+    m2, o2 = _model_from(U0, V0, dev, 1e-3, 1e-5)
+    b2 = engine.AdamBinding(m2, o2)
+    engine.train_steps(b2, st.dev[: B * 20], B)            # short: streaming (and sets the binding's fast path)
+    assert b2._big.ws is None
+    got = engine.train_steps(b2, st.dev, B).clone()        # long: the big form, although a fast path exists
+    assert b2._big.ws is not None and b2.step == 320
+    engine.check_status()
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    for nm, a, b in (("U", m2.U, model.U), ("V", m2.V, model.V)):
+        assert_close_with_rare_outliers(a.data.cpu().numpy(), b.data.cpu().numpy(), 2e-6, 1e-3, nm)
+    # a C2-shaped model is never offered the form
+    U1, V1, u1, i1, j1, z1 = _synthetic(4096, 4096, 64, B * 300, seed=5)
+    m3, o3 = _model_from(U1, V1, dev, 1e-3, 1e-5)
+    b3 = engine.AdamBinding(m3, o3)
+    engine.train_steps(b3, _records(u1, i1, j1, z1, 4096, 4096, dev).dev, B)
+    assert b3._big is False
+
+
 def test_big_resident_form_refuses_streams_that_concentrate_on_one_wave(dev):
     """A small table puts dozens of a batch's rows into one wave's slice: the form says so (status 2 -> MfcdError)
     instead of running out of gradient slots; shapes it does not take raise NotImplementedError."""
