@@ -701,7 +701,8 @@ def _run(args):
     big = getattr(runner.bind, "_big", None)
     used_big = bool(big) and big.ws is not None and longest >= engine.BIG_MIN_STEPS     # engine.train_steps took csrc/big.hip
     if used_big:
-        plan = dict(plan, form_name="big-resident")
+        # (the library's plan describes its own forms; the arithmetic flavour is the resident forms' global switch)
+        plan = dict(plan, form_name="big-resident", fast_math=engine.train_plan(64 * 300, 64, 4096, 4096, 64)["fast_math"])
     out = {
         "metric": "triplet-updates/sec", "value": round(consumed / dt, 1), "unit": "triplet-updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 6),

@@ -47,4 +47,6 @@ for name, n, m in (("C4: 65536 x 65536", 65536, 65536), ("32768 x 32768", 32768,
             engine.set_train_path("auto")
             engine.set_resident_math("fast")
     plan = engine.train_plan(N, B, n, m, d)["form_name"]
+    if plan == "streaming" and n + m <= 131072:
+        plan = "big resident, chosen by engine.train_steps"
     print(f"{name:20s} streaming {out['streaming']:7.2f}   auto ({plan}) {out['auto']:7.2f}   big resident {out['big']:7.2f} (IEEE flavour {out['big_ieee']:7.2f})", flush=True)
