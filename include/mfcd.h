@@ -15,7 +15,8 @@
  *    mfcd_error_string() renders either;
  *  - all work is enqueued on `stream` (a hipStream_t, may be NULL = default stream); no entry
  *    synchronises the host with the device except where its comment says so (mfcd_train_steps_timed;
- *    the bounded run-ahead of mfcd_train_steps; mfcd_shard_train_steps reads its collision marks once per call);
+ *    the bounded run-ahead of mfcd_train_steps; mfcd_shard_train_steps reads its collision marks once per call;
+ *    mfcd_train_steps_big copies its per-step table from the stack);
  *  - factor tables are row-major contiguous fp32: U [n][d], V [m][d];
  *  - a sample is the 16-byte record mfcd_sample {int32 u, i, j; float z} (reference batch tuple
  *    (u, i, j, z), structure.py:527-531, with the label already cast to fp32 as at 849);
