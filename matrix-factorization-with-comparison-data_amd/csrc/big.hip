@@ -73,16 +73,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     bool alive = true;
+    // the batch records and Adam scalars of a step are requested one step ahead: their load latency sits under the
+    // previous step's sweep instead of in front of every step
+    mfcd_sample s_next;
+    s_next.u = s_next.i = s_next.j = -1;
+    s_next.z = 0.0f;
+    if (lane < (a.N < a.B ? (int)a.N : a.B)) s_next = a.samples[lane];
+    StepScalars sc_next = a.sc[0];
     for (int k = 0; k < a.K && alive; ++k) {
         const long long pos0 = (long long)k * a.B;
         const int Bk = (int)((a.N - pos0) < a.B ? (a.N - pos0) : a.B);
         const unsigned tag = (unsigned)k + 1u;
-        const StepScalars sc = a.sc[k];
+        const StepScalars sc = sc_next;
         // ---- which samples of the batch name my rows? (one lane per sample, virtual ids: users first, then items)
-        mfcd_sample s;
-        s.u = s.i = s.j = -1;
-        s.z = 0.0f;
-        if (lane < Bk) s = a.samples[pos0 + lane];
+        const mfcd_sample s = s_next;
+        if (k + 1 < a.K) {
+            const long long pos1 = pos0 + a.B;
+            const int B1 = (int)((a.N - pos1) < a.B ? (a.N - pos1) : a.B);
+            s_next.u = s_next.i = s_next.j = -1;
+            s_next.z = 0.0f;
+            if (lane < B1) s_next = a.samples[pos1 + lane];
+            sc_next = a.sc[k + 1];
+        }
         const int vu = s.u - Rlo, vi = s.i + a.n - Rlo, vj = s.j + a.n - Rlo;
         const bool ou = lane < Bk && vu >= 0 && vu < kRows;
         const bool oi = lane < Bk && vi >= 0 && vi < kRows;
@@ -185,15 +197,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 
         // ---- dense Adam over my 128 rows; the few rows the batch named take their sparse gradient from LDS
-        // (rows in groups of four, each group's LDS reads issued together and nothing moved across a group's end: the
-        // scheduler would otherwise hoist dozens of reads and spill state registers to make room)
+        // (rows in groups of kG, each group's LDS reads issued together and nothing moved across a group's end: the
+        // scheduler would otherwise hoist dozens of reads and spill state registers to make room.  A lone wave per SIMD
+        // has nobody to hide its dependent chains behind: kG / 2 independent packed chains per group do that.)
+        constexpr int kG = 8;
 #pragma unroll
-        for (int q0 = 0; q0 < kRows; q0 += 4) {
-            float pq[4], gq[4];
+        for (int q0 = 0; q0 < kRows; q0 += kG) {
+            float pq[kG], gq[kG];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) pq[x] = prow[(q0 + x) * kD + lane];
+            for (int x = 0; x < kG; ++x) pq[x] = prow[(q0 + x) * kD + lane];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
+            for (int x = 0; x < kG; ++x) {
                 const int q = q0 + x;
                 gq[x] = 0.0f;
                 const u64 hm = q < 64 ? hit_lo : hit_hi;
@@ -206,14 +220,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
             if constexpr (FAST) {
-                adam_update_fast2(pq[0], pq[1], m1[q0], m1[q0 + 1], m2[q0], m2[q0 + 1], gq[0], gq[1], a.ac, sc);
-                adam_update_fast2(pq[2], pq[3], m1[q0 + 2], m1[q0 + 3], m2[q0 + 2], m2[q0 + 3], gq[2], gq[3], a.ac, sc);
+#pragma unroll
+                for (int x = 0; x < kG; x += 2)
+                    adam_update_fast2(pq[x], pq[x + 1], m1[q0 + x], m1[q0 + x + 1], m2[q0 + x], m2[q0 + x + 1], gq[x], gq[x + 1],
+                                      a.ac, sc);
             } else {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) adam_update(pq[x], m1[q0 + x], m2[q0 + x], gq[x], a.ac, sc);
+                for (int x = 0; x < kG; ++x) adam_update(pq[x], m1[q0 + x], m2[q0 + x], gq[x], a.ac, sc);
             }
 #pragma unroll
-            for (int x = 0; x < 4; ++x) prow[(q0 + x) * kD + lane] = pq[x];
+            for (int x = 0; x < kG; ++x) prow[(q0 + x) * kD + lane] = pq[x];
             asm volatile("" ::: "memory");
         }
     }
