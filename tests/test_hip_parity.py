@@ -1269,6 +1269,37 @@ def test_auto_takes_the_big_resident_form_for_c4_sized_states(dev):
     assert b3._big is False
 
 
+def test_train_model_on_a_c4_sized_model_goes_through_the_big_resident_form(dev):
+    """structure.train_model (epoch loop, shuffling, validation passes, staged prologues of mfcd.engine.fit) on a C4-shaped
+    model with epochs of 300 steps: the big resident form carries the epochs, and losses / factors agree with the run that
+    streams (`set_big_resident("off")`) within the resident tolerance."""
+    import structure as S
+    from mfcd import engine
+    n = m = 65536
+    d, B = 64, 64
+    N = B * 300 + 17
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N + 640, seed=91)
+    rows = np.stack([u, i, j, z], 1)
+    mk = lambda r, sh: torch.utils.data.DataLoader(ListDataset(r), batch_size=B, shuffle=sh)   # noqa: E731
+    out = {}
+    for mode in ("off", "auto"):
+        engine.set_big_resident(mode)
+        try:
+            torch.manual_seed(3)
+            model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+            tl, vl = S.train_model(model, mk(rows[:N], True), mk(rows[N:], False), opt, dev, num_epochs=3)
+            engine.check_status()
+        finally:
+            engine.set_big_resident("auto")
+        out[mode] = (np.asarray(tl), np.asarray(vl), model.U.data.cpu().numpy(), model.V.data.cpu().numpy(),
+                     float(opt.state[model.U]["step"]))
+    assert out["auto"][4] == out["off"][4] == 3 * 301
+    np.testing.assert_allclose(out["auto"][0], out["off"][0], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["auto"][1], out["off"][1], rtol=2e-5, atol=2e-6)
+    assert_close_with_rare_outliers(out["auto"][2], out["off"][2], 3e-6, 1e-3, "U")
+    assert_close_with_rare_outliers(out["auto"][3], out["off"][3], 3e-6, 1e-3, "V")
+
+
 def test_big_resident_form_refuses_streams_that_concentrate_on_one_wave(dev):
     """A small table puts dozens of a batch's rows into one wave's slice: the form says so (status 2 -> MfcdError)
     instead of running out of gradient slots; shapes it does not take raise NotImplementedError."""
