@@ -13,7 +13,8 @@ def cp(src, dst):
 
 
 for tag, name in (("prof_driver", "r03_bench_c2_driver_cmd_kernel_stats.csv"), ("prof_bench", "r03_bench_c2_kernel_stats.csv"),
-                  ("prof_c3", "r03_bench_c3_kernel_stats.csv"), ("prof_uvt", "r03_uvt_pass_kernel_stats.csv")):
+                  ("prof_c3", "r03_bench_c3_kernel_stats.csv"), ("prof_c4", "r03_bench_c4_kernel_stats.csv"),
+                  ("prof_uvt", "r03_uvt_pass_kernel_stats.csv")):
     if glob.glob(f"{E}/{tag}/**/*_kernel_stats.csv", recursive=True):      # a section that was not re-collected keeps its file
         cp(newest(f"{E}/{tag}/**/*_kernel_stats.csv"), name)
 for name in ("bench_c2_default.json", "bench_c2_driver_cmd.json", "bench_c2_driver_cmd_under_rocprof.json",

@@ -16,6 +16,8 @@ timeout -k 10 300 python bench.py --dp-mode shard --no-cpu-baseline --steps 2098
 timeout -k 10 300 python bench.py --workload C4 --dp-mode shard --no-cpu-baseline --no-extras --steps 2000 --warmup 200 > $E/bench_c4_shard_one_rank.json 2>/dev/null; cut -c1-200 $E/bench_c4_shard_one_rank.json
 timeout -k 10 300 python bench.py --workload C4 --dp-mode shard --tune shard_pipeline=0 --no-cpu-baseline --no-extras --steps 2000 --warmup 200 > $E/bench_c4_shard_one_rank_strict.json 2>/dev/null; cut -c1-200 $E/bench_c4_shard_one_rank_strict.json
 timeout -k 10 300 python tools/bench_samplers.py > $E/samplers.txt 2>&1; tail -6 $E/samplers.txt
+timeout -k 10 300 python tools/bench_big.py 2000 > $E/big_resident.txt 2>&1; tail -4 $E/big_resident.txt
+timeout -k 10 300 python tools/exp_chain_depth.py > $E/chain_depth_experiment.txt 2>&1; tail -3 $E/chain_depth_experiment.txt
 timeout -k 10 300 python tools/bench_uvt.py > $E/uvt_pass_roofline.txt 2>&1; cat $E/uvt_pass_roofline.txt | cut -c1-240
 timeout -k 10 300 python tools/bench_metrics.py > $E/metric_functions_c2.txt 2>&1; cat $E/metric_functions_c2.txt
 timeout -k 10 400 python tools/bench_metrics_c5.py > $E/metric_functions_c5.txt 2>&1; tail -6 $E/metric_functions_c5.txt
@@ -38,6 +40,7 @@ if [ "$1" = "prof" ]; then
 $P --stats -d $E/prof_driver -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $E/bench_c2_driver_cmd_under_rocprof.json 2>/dev/null
 $P --stats -d $E/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-extras > $E/bench_c2_under_rocprof.json 2>/dev/null
 $P --stats -d $E/prof_c3 -- python3 $R/bench.py --workload C3 --steps 3356 --warmup 1678 --no-cpu-baseline --no-extras > /dev/null 2>&1
+$P --stats -d $E/prof_c4 -- python3 $R/bench.py --workload C4 --steps 4000 --warmup 300 --no-cpu-baseline --no-extras > /dev/null 2>&1
 MFCD_SKIP_TORCH=1 UVT_BENCH_SECONDS=0.01 $P --stats -d $E/prof_uvt -- python3 $R/tools/bench_uvt.py C2 C3 C5 > /dev/null 2>&1
 fi
 if [ "$1" = "pmc" ]; then
