@@ -1300,6 +1300,33 @@ def test_train_model_on_a_c4_sized_model_goes_through_the_big_resident_form(dev)
     assert_close_with_rare_outliers(out["auto"][3], out["off"][3], 3e-6, 1e-3, "V")
 
 
+def test_auto_streams_a_c4_sized_model_when_the_stream_concentrates_on_few_rows(dev):
+    """A Zipf-head stream (item 0 in ~40 % of the samples, hundreds of references into one wave's slice per batch) fails
+    the big form's pre-check: "auto" must stream such calls — bit-identical to the forced streaming path — and say
+    nothing."""
+    from mfcd import engine
+    n = m = 65536
+    d, B = 64, 64
+    N = B * 260
+    U0, V0, u, i, j, z = _synthetic(n, m, d, N, seed=12)
+    rng = np.random.default_rng(5)
+    i = np.where(rng.random(N) < 0.4, 0, i)
+    j = np.where(i == j, (j + 1) % m, j)
+    st = _records(u, i, j, z, n, m, dev)
+    engine.set_train_path("streaming")
+    try:
+        model, opt = _model_from(U0, V0, dev, 1e-3, 1e-5)
+        ref = engine.train_steps(engine.AdamBinding(model, opt), st.dev, B).clone()
+    finally:
+        engine.set_train_path("auto")
+    m2, o2 = _model_from(U0, V0, dev, 1e-3, 1e-5)
+    b2 = engine.AdamBinding(m2, o2)
+    got = engine.train_steps(b2, st.dev, B).clone()
+    engine.check_status()
+    assert b2._big is not False and b2._big.ws is None          # offered, pre-check said no, never launched
+    assert torch.equal(got, ref) and torch.equal(m2.U.data, model.U.data) and torch.equal(m2.V.data, model.V.data)
+
+
 def test_big_resident_form_refuses_streams_that_concentrate_on_one_wave(dev):
     """A small table puts dozens of a batch's rows into one wave's slice: the form says so (status 2 -> MfcdError)
     instead of running out of gradient slots; shapes it does not take raise NotImplementedError."""
