@@ -583,8 +583,9 @@ def _bench_independent_replicas(cfg, dev, steps, warmup, seed):
     dt, total = float(tmax[0].item()), float(t[1].item())
     return {"value": round(total / dt, 1), "unit": "triplet-updates/s", "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 6),
             "scaling": "weak", "collectives_on_the_data_path": 0,
-            "step_form": engine.train_plan(min(steps, runner.steps_per_epoch) * cfg["B"], cfg["B"], cfg["n"], cfg["m"],
-                                           cfg["d"])["form_name"],
+            "step_form": ("big-resident" if getattr(runner.bind, "_big", None) and runner.bind._big.ws is not None else
+                          engine.train_plan(min(steps, runner.steps_per_epoch) * cfg["B"], cfg["B"], cfg["n"], cfg["m"],
+                                            cfg["d"])["form_name"]),
             "what": "one independent training run per rank (own model, own samples, batch 64, the single-GPU step form): "
                     "the way the reference's parameter scans spread over GPUs (structure.scan_over_ranks)"}
 
@@ -719,6 +720,12 @@ def bench_data_parallel(cfg, dev, steps, warmup, seed, mode="native", extras=Tru
             c4 = dict(bench_mod.C4, name="C4")
             sub = {}
             forms = ("native", "shard_strict", "shard") if mode != "allgather" else ("allgather",)
+            try:    # what ONE GPU does with C4 on its own (the big resident form, csrc/big.hip), on every rank at once
+                r = _bench_independent_replicas(c4, dev, 600, 300, seed)
+                sub["independent_replicas"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling",
+                                                                 "collectives_on_the_data_path", "step_form", "what")}
+            except Exception as e:
+                sub["independent_replicas"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             for form in forms:
                 try:
                     engine.set_tuning(shard_pipeline=0 if form == "shard_strict" else 1)
