@@ -201,11 +201,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // scheduler would otherwise hoist dozens of reads and spill state registers to make room.  A lone wave per SIMD
         // has nobody to hide its dependent chains behind: kG / 2 independent packed chains per group do that.)
         constexpr int kG = 8;
+        // two register sets: the next group's parameters are read from LDS while this group is updated (a lone wave has
+        // nobody to hide the LDS latency behind: the counters showed 44 % of its cycles in s_waitcnt without this)
+        float pa[kG], pb[kG];
 #pragma unroll
-        for (int q0 = 0; q0 < kRows; q0 += kG) {
-            float pq[kG], gq[kG];
+        for (int x = 0; x < kG; ++x) pa[x] = prow[x * kD + lane];
 #pragma unroll
-            for (int x = 0; x < kG; ++x) pq[x] = prow[(q0 + x) * kD + lane];
+        for (int g8 = 0; g8 < kRows / kG; ++g8) {
+            const int q0 = g8 * kG;
+            float (&pq)[kG] = (g8 & 1) ? pb : pa;
+            float (&pn)[kG] = (g8 & 1) ? pa : pb;
+            if (g8 + 1 < kRows / kG) {
+#pragma unroll
+                for (int x = 0; x < kG; ++x) pn[x] = prow[(q0 + kG + x) * kD + lane];
+            }
+            float gq[kG];
 #pragma unroll
             for (int x = 0; x < kG; ++x) {
                 const int q = q0 + x;
