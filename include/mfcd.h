@@ -503,9 +503,9 @@ int mfcd_sample_triplets(const mfcd_sampler *law, const int64_t *barred_keys, in
  * Register-resident optimiser steps for states of up to 8 388 608 elements at d = 64 (round 3, opt-in: BASELINE
  * configs[3], n = m = 65536, d = 64, is exactly 1 024 SIMDs x 64 lanes x 128 rows).  The step of mfcd_train_steps
  * (structure.py:845-852) with the arithmetic of its streaming form (bit-identical results), as ONE persistent launch of
- * one wave per SIMD: exp_avg / exp_avg_sq of a wave's 128 rows in 256 registers per lane (VGPRs + AccVGPRs), the
+ * two waves per SIMD: exp_avg / exp_avg_sq of a wave's 64 rows in 128 registers per lane, the
  * parameters in LDS, rows exchanged per step through tagged granules (publish right before use).  fp32 tables, d == 64,
- * n + m <= 131072, B <= 64; a batch may name at most 16 distinct rows of one wave (else status 2 and the call is void:
+ * n + m <= 131072, B <= 64; a batch may name at most mfcd_train_big_slots() (8) distinct rows of one wave's 64-row slice (else status 2 and the call is void:
  * streams that concentrate on a few rows belong to the streaming form).  The call waits once on the host (its per-step
  * table is copied from the stack).  workspace: mfcd_train_big_workspace_bytes(N, B) — status word (int32, first 4
  * bytes; mfcd_train_big_status reads it: 0 ok, 1 a bounded wait expired, 2 too many rows of one wave in a batch), the
@@ -518,7 +518,7 @@ int mfcd_train_steps_big(float *U, float *V, float *mU, float *vU, float *mV, fl
                          void *stream);
 int mfcd_train_big_status(const void *workspace, int *status_out, void *stream);
 /* pre-check of a sample stream for the form above: *max_out_dev (device int32) = the largest number of row references
- * one wave's 128-row slice receives from one batch (an upper bound of the distinct rows); the form takes the call when
+ * one wave's 64-row slice receives from one batch (an upper bound of the distinct rows); the form takes the call when
  * it is <= mfcd_train_big_slots(). */
 int mfcd_train_big_slots(void);
 int mfcd_train_big_check(const mfcd_sample *samples, int64_t N, int B, int n, int m, int *max_out_dev, void *stream);

@@ -3,12 +3,14 @@
 //
 // Same step as mfcd_train_steps (structure.py:845-852: forward, BCE, backward, dense coupled-L2 Adam) and the same
 // arithmetic as its streaming form (adam_update, sigmoid_f32, bce_*: results are bit-identical to it), but the Adam state
-// never leaves the chip during a call: ONE persistent launch of 1 024 waves, one per SIMD, each owning 128 rows of the
-// virtual table [U; V]:
-//   * exp_avg and exp_avg_sq of the slice live in 2 x 128 registers per lane (a lone wave addresses 512: the compiler
-//     places what does not fit the 256 architectural VGPRs in AccVGPRs), at compile-time indices of the unrolled sweep;
-//   * the parameters of the slice live in LDS (32 KB per wave, 128 KB per workgroup of four waves), where the sparse
-//     part of the step — hits of the batch on this wave's rows — can address a row by number;
+// never leaves the chip during a call: ONE persistent launch of 2 048 waves, two per SIMD, each owning 64 rows of the
+// virtual table [U; V] (MFCD_BIG_ROWS = 128: 1 024 waves, one per SIMD, 128 rows each — the first form built; a lone
+// wave leaves its dependent chains' bubbles unfilled: 9.5 us per step at C4 against 5.9 for two waves of 64 rows):
+//   * exp_avg and exp_avg_sq of the slice live in 2 x 64 registers per lane (2 x 128 at one wave per SIMD, where a lone
+//     wave addresses 512 and the compiler places what does not fit the 256 architectural VGPRs in AccVGPRs), at
+//     compile-time indices of the unrolled sweep;
+//   * the parameters of the slice live in LDS (16 KB per wave, 64 KB per workgroup of four waves, two workgroups per
+//     CU), where the sparse part of the step — hits of the batch on this wave's rows — can address a row by number;
 //   * per step: every wave scans the batch's <= 64 records (one lane per sample), publishes the rows it owns that the
 //     batch names (state after the previous step) as tagged 8-byte granules into the sample's mailbox slot, polls the
 //     slots of the rows it does not own (bounded spins, sticky abort word), forms the coefficient and accumulates its
@@ -24,10 +26,16 @@
 namespace {
 
 typedef unsigned long long u64;
-constexpr int kRows = 128;          // rows (= registers per state array) per wave
+#ifndef MFCD_BIG_ROWS
+#define MFCD_BIG_ROWS 64      // measured at C4: 64-row slices at two waves per SIMD 5.9 us per step, 128-row slices at one 9.5
+#endif
+constexpr int kRows = MFCD_BIG_ROWS;                 // rows (= registers per state array) per wave: 128 or 64
+constexpr int kRowsLog2 = kRows == 128 ? 7 : 6;
 constexpr int kD = 64;
-constexpr int kWaves = 1024;        // one per SIMD of the 256 CUs
-constexpr int kSlots = 16;          // distinct rows of a wave one batch may touch (more: the call is refused)
+constexpr int kWavesPerSimd = 128 / kRows;           // 1 (512 registers per lane) or 2 (256 each)
+constexpr int kWaves = 1024 * kWavesPerSimd;         // over the 1 024 SIMDs of the 256 CUs
+constexpr int kSlots = kRows == 128 ? 16 : 8;        // distinct rows of a wave one batch may touch (more: the call is refused)
+static_assert(kRows == 128 || kRows == 64, "slices of 128 or 64 rows");
 constexpr unsigned kSpinLimit = 1u << 22;
 
 struct BigArgs {
@@ -47,7 +55,7 @@ __device__ __forceinline__ u64 pack(unsigned tag, float v) { return ((u64)tag <<
 // FAST: the resident form's arithmetic (hardware sqrt / rcp / exp2 with one Newton correction per quotient, packed pairs:
 // a few ulp from the IEEE sequence, ~3x fewer issue slots); !FAST: the streaming form's IEEE sequence, bit-identical to it.
 template <bool FAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void big_train_kernel(BigArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWavesPerSimd, kWavesPerSimd))) void big_train_kernel(BigArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         ++nslots;
                         grad[sl * kD + lane] = 0.0f;
                         if (lr[r] < 64) hit_lo |= 1ull << lr[r];
-                        else hit_hi |= 1ull << (lr[r] - 64);
+                        else hit_hi |= 1ull << (lr[r] & 63);
                     }
                     grad[sl * kD + lane] += contrib[r];
                 }
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void big_check_kernel(const mfcd_sample *__res
         const mfcd_sample s = samples[off + x / 3];
         const int role = x % 3;
         const int v = role == 0 ? s.u : n + (role == 1 ? s.i : s.j);
-        if (v >= 0 && (v >> 7) < kWaves) atomicAdd(&bins[v >> 7], 1);
+        if (v >= 0 && (v >> kRowsLog2) < kWaves) atomicAdd(&bins[v >> kRowsLog2], 1);
     }
     __syncthreads();
     int mx = 0;
@@ -338,7 +346,7 @@ extern "C" int mfcd_train_steps_big(float *U, float *V, float *mU, float *vU, fl
         MFCD_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         MFCD_HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
         MFCD_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, kLds));
-        if (cus * nb < kWaves / 4) return MFCD_EINVAL;
+        if (cus * nb < kWaves / 4 || nb < kWavesPerSimd) return MFCD_EINVAL;
         checked[fast] = 1;
     }
     char *ws = (char *)workspace;

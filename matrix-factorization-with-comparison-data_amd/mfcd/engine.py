@@ -230,7 +230,7 @@ class BigResident:
         _lib.check(self.L.mfcd_train_big_status(_lib.ptr(self.ws), ctypes.byref(out), _lib.stream_ptr(self.dev)))
         if out.value:
             raise _lib.MfcdError({1: "big resident form: a bounded wait expired",
-                                  2: "big resident form: a batch named more than 16 distinct rows of one wave"}.get(
+                                  2: "big resident form: a batch named more rows of one wave's slice than it has gradient slots for"}.get(
                                       out.value, f"big resident form: status {out.value}"))
 
 
