@@ -30,12 +30,12 @@ typedef unsigned long long u64;
 #define MFCD_BIG_ROWS 64      // measured at C4: 64-row slices at two waves per SIMD 5.9 us per step, 128-row slices at one 9.5
 #endif
 constexpr int kRows = MFCD_BIG_ROWS;                 // rows (= registers per state array) per wave: 128 or 64
-constexpr int kRowsLog2 = kRows == 128 ? 7 : 6;
+constexpr int kRowsLog2 = kRows == 128 ? 7 : (kRows == 64 ? 6 : 5);
 constexpr int kD = 64;
 constexpr int kWavesPerSimd = 128 / kRows;           // 1 (512 registers per lane) or 2 (256 each)
 constexpr int kWaves = 1024 * kWavesPerSimd;         // over the 1 024 SIMDs of the 256 CUs
-constexpr int kSlots = kRows == 128 ? 16 : 8;        // distinct rows of a wave one batch may touch (more: the call is refused)
-static_assert(kRows == 128 || kRows == 64, "slices of 128 or 64 rows");
+constexpr int kSlots = kRows == 128 ? 16 : (kRows == 64 ? 8 : 6);   // distinct rows of a wave one batch may touch (more: the call is refused)
+static_assert(kRows == 128 || kRows == 64 || kRows == 32, "slices of 128, 64 or 32 rows");
 constexpr unsigned kSpinLimit = 1u << 22;
 
 struct BigArgs {
